@@ -1,0 +1,106 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (imported under tools/ref_shim.py, in the build
+container only).  Each fixture holds inputs (config, seed) and the reference's outputs: per ply the root
+statistics MCTS.run returned (N, W, P by policy index, root.visits), the move played, and the final
+Self_Play arrays (input states, improved policies, q, z, values, game_stats) — data only.
+
+    python tools/gen_golden.py            # regenerate everything
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from tools import ref_shim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+GAME_CLASS = {"TicTacToe": ("TicTacToe", "TicTacToe"), "Connect4": ("Connect4", "Connect4"), "Gomoku": ("Gomoku", "Gomoku")}
+
+
+def action_to_index(game, action):
+    if game == "Connect4":
+        return int(action)
+    W = 3 if game == "TicTacToe" else 15
+    x, y = int(action[0]), int(action[1])
+    return y * W + x
+
+
+def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore_second, c_puct_init, alpha,
+                      seed, slot, game_seq, salt, session=None):
+    """Run the reference's Self_Play.play() once; returns the fixture dict."""
+    ref = ref_shim.load_reference()
+    inj = ref_shim.activate(seed, slot, game_seq)
+    cls = getattr(ref[GAME_CLASS[game][0]], GAME_CLASS[game][1])
+    g = cls()
+    A = g.policy_shape[0]
+    sess = session if session is not None else ref_shim.HashSession(A, salt)
+    train_config = {"MCTS_iteration_limit": iteration_limit, "MCTS_time_limit": None, "use_gumbel": False,
+                    "use_njit": False, "c_puct_init": c_puct_init, "dirichlet_alpha": alpha,
+                    "max_actions": max_actions, "num_explore_actions_first": explore_first,
+                    "num_explore_actions_second": explore_second}
+    build_config = {}
+    folder = f"/fake/{game}_{iteration_limit}_{seed}_{slot}_{game_seq}/1"
+    ref_shim._FakeH5File.STORE.pop(folder + "/Self_Play_Data.h5", None)
+    f = ref_shim._FakeH5File(folder + "/Self_Play_Data.h5")
+    f.create_dataset("game_stats", data=np.zeros(6, np.uint32), dtype=np.uint32)
+
+    class _Lock:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    sp = ref["Self_Play"].Self_Play(g, sess, build_config, train_config, _Lock(), folder, 1)
+    sp.play()
+    T = len(g.action_history)
+    rN = np.zeros((T, A), np.uint32); rW = np.zeros((T, A), np.float32); rP = np.zeros((T, A), np.float32)
+    rV = np.zeros(T, np.uint64); acts = np.zeros(T, np.int32)
+    assert len(inj.run_log) == T
+    for t, (tree, (move, rows)) in enumerate(inj.run_log):
+        acts[t] = action_to_index(game, move)
+        for r in rows:
+            a = action_to_index(game, r[0])
+            rN[t, a] = r[4]; rW[t, a] = r[3]; rP[t, a] = r[5]
+        rV[t] = int(rows[0][6])
+    d = f.d
+    n_aug = (len(d) - 1) // 3
+    out = dict(game=game, iteration_limit=iteration_limit, run_iterations=int(iteration_limit * 1.5),
+               max_actions=max_actions, explore_first=explore_first, explore_second=explore_second,
+               c_puct_init=c_puct_init, dirichlet_alpha=alpha, seed=seed, slot=slot, game_seq=game_seq, salt=salt,
+               actions=acts, root_N=rN, root_W=rW, root_P=rP, root_visits=rV,
+               states=d["boards_0"].data, policies=d["policies_0"].data, values=d["values_0"].data,
+               game_stats=d["game_stats"].data, n_aug=n_aug, evaluator_calls=sess.calls)
+    for k in range(n_aug):
+        out[f"aug_boards_{k}"] = d[f"boards_{k}"].data
+        out[f"aug_policies_{k}"] = d[f"policies_{k}"].data
+    return out
+
+
+PUCT_CASES = [
+    # name, game, MCTS_iteration_limit, max_actions, explore_first, explore_second, c_puct_init, alpha, seed, slot, seq, salt
+    ("ttt_puct_a", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 1234, 0, 0, 7),       # int(34*1.5) = 51 ~ config[0]'s 50 sims
+    ("ttt_puct_b", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 1234, 3, 1, 7),
+    ("c4_puct_a", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 1234, 0, 0, 11),
+    ("c4_puct_b", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 1234, 5, 2, 11),
+    ("c4_puct_c", "Connect4", 134, 42, 8, 7, 2.5, 0.5, 99, 17, 0, 3),           # int(134*1.5) = 201 sims (headline n=200)
+    ("gmk_puct_a", "Gomoku", 40, 12, 6, 4, 4.5, 0.05, 1234, 0, 0, 5),
+]
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    only = set(sys.argv[1:])
+    for name, *cfg in PUCT_CASES:
+        if only and name not in only:
+            continue
+        fx = ref_selfplay_puct(*cfg)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "stats", fx["game_stats"], "evals", fx["evaluator_calls"], flush=True)
+
+
+if __name__ == "__main__":
+    main()
