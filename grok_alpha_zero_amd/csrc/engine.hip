@@ -1,0 +1,415 @@
+// engine.hip — host side of libgaz_engine.so: owns the HBM state, launches the wave kernel + evaluator
+// once per simulation wave on one HIP stream, and implements the C ABI of include/gaz_engine.h.
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/gaz_engine.h"
+#include "rt.hpp"
+#include "puct_core.hpp"
+#include "evaluator.hpp"
+
+using namespace gaz;
+
+static std::string g_create_error;
+
+#define HIP_OK(expr)                                                                  \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) { return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+
+// ------------------------------------------------------------------------------------------ kernels
+template <class G> GAZ_KERNEL k_wave(DevParams<G> E) {
+    GAZ_SHARED Scratch<G> S;
+    const int g = block_id();
+    if (g < E.n_games) game_step<G>(E, g, S);
+}
+
+template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
+    const int g = block_id();
+    if (g >= E.n_games || lane_id() != 0) return;
+    GameState<G>& gs = E.games[g];
+    memset(&gs, 0, sizeof(gs));
+    gs.phase = PH_NEW_GAME; gs.pend_kind = PEND_NONE; gs.game_seq = (uint32_t)first_seq; gs.host_move = -1; gs.winner = RUNNING;
+    E.trees[g * 2].root = -1; E.trees[g * 2 + 1].root = -1;
+}
+
+template <class G> GAZ_KERNEL k_reset_games(DevParams<G> E, const int32_t* slots, int n) {
+    const int i = block_id();
+    if (i >= n || lane_id() != 0) return;
+    const int g = slots ? slots[i] : i;
+    if (g < 0 || g >= E.n_games) return;
+    GameState<G>& gs = E.games[g];
+    const uint32_t seq = gs.game_seq + ((gs.phase == PH_NEW_GAME && gs.n_evals == 0) ? 0u : 1u);
+    const uint64_t ne = gs.n_evals, ns = gs.n_sims;
+    memset(&gs, 0, sizeof(gs));
+    gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns;
+}
+
+template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
+    const int g = block_id();
+    if (g >= E.n_games || lane_id() != 0) return;
+    GameState<G>& gs = E.games[g];
+    if (gs.phase == PH_WAIT_HOST) { gs.host_move = moves ? moves[g] : -1; gs.phase = PH_APPLY; }
+}
+
+// dense copies of the last MCTS.run result of every game (engine_get_root_stats)
+template <class G> GAZ_KERNEL k_gather_root(DevParams<G> E, uint32_t* oN, float* oW, float* oP, float* oPol, uint32_t* oRV,
+                                             float* oQ, int32_t* oChosen, int32_t* oPhase, int32_t* oPending) {
+    using RL = RecLayout<G>;
+    const int g = block_id();
+    if (g >= E.n_games) return;
+    const GameState<G>& gs = E.games[g];
+    const uint8_t* rec = E.recs + (size_t)g * RL::SIZE;
+    const int ply = gs.n_hist < G::MAXT ? gs.n_hist : G::MAXT - 1;
+    for (int a = lane_id(); a < G::A; a += WAVE) {
+        oN[(size_t)g * G::A + a] = reinterpret_cast<const uint32_t*>(rec + RL::OFF_N)[(size_t)ply * G::A + a];
+        oW[(size_t)g * G::A + a] = reinterpret_cast<const float*>(rec + RL::OFF_W)[(size_t)ply * G::A + a];
+        oP[(size_t)g * G::A + a] = reinterpret_cast<const float*>(rec + RL::OFF_P)[(size_t)ply * G::A + a];
+        oPol[(size_t)g * G::A + a] = reinterpret_cast<const float*>(rec + RL::OFF_POL)[(size_t)ply * G::A + a];
+    }
+    if (lane_id() == 0) {
+        oRV[g] = reinterpret_cast<const uint32_t*>(rec + RL::OFF_RV)[ply];
+        oQ[g] = reinterpret_cast<const float*>(rec + RL::OFF_Q)[ply];
+        oChosen[g] = gs.chosen; oPhase[g] = gs.phase; oPending[g] = gs.pend_kind;
+    }
+}
+
+template <class G> GAZ_KERNEL k_count(DevParams<G> E, int32_t* out) {   // out[0] = games still searching, out[1] = pending evals
+    const int g = block_id();
+    if (g >= E.n_games || lane_id() != 0) return;
+    const GameState<G>& gs = E.games[g];
+    if (gs.phase != PH_WAIT_HOST && gs.phase != PH_HALT) atomic_add(&out[0], 1);
+    if (gs.pend_kind != PEND_NONE) atomic_add(&out[1], 1);
+    atomic_add(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)gs.n_evals);
+    atomic_add(reinterpret_cast<unsigned long long*>(out + 4), (unsigned long long)gs.n_sims);
+}
+
+// ------------------------------------------------------------------------------------------ engine
+struct gaz_engine {
+    gaz_engine_config cfg;
+    std::string err;
+    virtual ~gaz_engine() {}
+    int fail(const std::string& m) { err = m; return 1; }
+    virtual int init() = 0;
+    virtual int load_weights(const gaz_tensor* t, int n) = 0;
+    virtual int reset_games(const int32_t* slots, int n) = 0;
+    virtual int run_move(int32_t* n_waiting) = 0;
+    virtual int get_root_stats(uint32_t*, float*, float*, float*, uint32_t*, float*, int32_t*, int32_t*) = 0;
+    virtual int apply_moves(const int32_t* moves) = 0;
+    virtual int run_waves(int n) = 0;
+    virtual int wave_begin() = 0;
+    virtual int wave_end() = 0;
+    virtual int batch_ptrs(void**, void**, void**) = 0;
+    virtual int read_batch(int8_t*, int32_t*) = 0;
+    virtual int write_outputs(const float*, const float*) = 0;
+    virtual int record_layout(gaz_record_layout*) = 0;
+    virtual int drain(void* out, int max_records, int32_t* n_out) = 0;
+    virtual int get_stats(uint64_t out[8]) = 0;
+    virtual int synchronize() = 0;
+    virtual int timing_reset(int enable) = 0;
+    virtual int timing_get(double*, double*, double*, int64_t*, int64_t*) = 0;
+};
+
+template <class G> struct EngineT : gaz_engine {
+    using RL = RecLayout<G>;
+    DevParams<G> E;
+    hipStream_t stream = 0;
+    Evaluator* eval = nullptr;
+    // dense scratch for get_root_stats / counters
+    uint32_t* dN = nullptr; float* dW = nullptr; float* dP = nullptr; float* dPol = nullptr; uint32_t* dRV = nullptr;
+    float* dQ = nullptr; int32_t* dChosen = nullptr; int32_t* dPhase = nullptr; int32_t* dPending = nullptr;
+    int32_t* dCount = nullptr; int32_t* dMoves = nullptr; int32_t* dSlots = nullptr;
+    uint32_t ring_consumed = 0;
+    bool timing = false;
+    std::vector<hipEvent_t> ev;      // triples: before tree, after tree, after eval
+    int64_t n_waves_total = 0;
+    std::vector<void*> allocs;
+
+    template <class T> int dalloc(T** p, size_t n) {
+        void* q = nullptr;
+        HIP_OK(hipMalloc(&q, n * sizeof(T)));
+        HIP_OK(hipMemset(q, 0, n * sizeof(T)));
+        allocs.push_back(q); *p = (T*)q; return 0;
+    }
+
+    ~EngineT() override {
+        hipStreamSynchronize(stream);
+        delete eval;
+        for (void* p : allocs) hipFree(p);
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+        hipStreamDestroy(stream);
+    }
+
+    int init() override {
+        HIP_OK(hipSetDevice(cfg.device));
+        HIP_OK(hipStreamCreate(&stream));
+        memset(&E, 0, sizeof(E));
+        const int n = cfg.n_games;
+        if (n <= 0) return fail("n_games must be positive");
+        if (cfg.search != GAZ_SEARCH_PUCT) return fail("search: only GAZ_SEARCH_PUCT is built in this library version");
+        E.n_games = n; E.run_iterations = cfg.run_iterations; E.max_actions = cfg.max_actions;
+        if (cfg.max_actions > G::MAXT || cfg.max_actions <= 0) return fail("max_actions out of range for this game");
+        E.explore_first = cfg.num_explore_actions_first; E.explore_second = cfg.num_explore_actions_second;
+        E.create_new_root = cfg.create_new_root; E.sync_moves = cfg.sync_moves; E.use_dirichlet = cfg.use_dirichlet;
+        int npt = cfg.nodes_per_tree;
+        if (npt <= 0) {   // a tree lives for the whole game and gains <= 1 record per simulation of its own moves
+            const int own_moves = (cfg.max_actions + 1) / 2 + 1;
+            int its = cfg.run_iterations < 3 * G::A ? 3 * G::A : cfg.run_iterations;
+            npt = own_moves * (its + 2) + 64;
+        }
+        E.nodes_per_tree = npt;
+        E.ring_cap = cfg.ring_capacity;
+        E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
+        E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
+        E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
+        E.key0 = (uint32_t)cfg.seed; E.key1 = (uint32_t)(cfg.seed >> 32); E.slot_offset = cfg.slot_offset;
+        const size_t arena_bytes = (size_t)n * 2 * (size_t)npt * NodeLayout<G>::SIZE;
+        void* a = nullptr;
+        HIP_OK(hipMalloc(&a, arena_bytes));               // not zeroed: every record is written before it is read
+        allocs.push_back(a); E.arena = (uint8_t*)a;
+        if (dalloc(&E.trees, (size_t)n * 2)) return 1;
+        if (dalloc(&E.games, (size_t)n)) return 1;
+        if (dalloc(&E.paths, (size_t)n * PATH_CAP)) return 1;
+        if (dalloc(&E.recs, (size_t)n * RL::SIZE)) return 1;
+        if (dalloc(&E.ring, (size_t)(cfg.ring_capacity > 0 ? cfg.ring_capacity : 1) * RL::SIZE)) return 1;
+        if (dalloc(&E.ring_head, 4)) return 1;
+        if (dalloc(&E.nn_in, (size_t)n * G::HW * G::C + 64)) return 1;
+        if (dalloc(&E.nn_policy, (size_t)n * G::A + 64)) return 1;
+        if (dalloc(&E.nn_value, (size_t)n + 64)) return 1;
+        if (dalloc(&E.stats, 8)) return 1;
+        if (dalloc(&E.error, 4)) return 1;
+        if (dalloc(&dN, (size_t)n * G::A) || dalloc(&dW, (size_t)n * G::A) || dalloc(&dP, (size_t)n * G::A) ||
+            dalloc(&dPol, (size_t)n * G::A) || dalloc(&dRV, n) || dalloc(&dQ, n) || dalloc(&dChosen, n) ||
+            dalloc(&dPhase, n) || dalloc(&dPending, n) || dalloc(&dCount, 8) || dalloc(&dMoves, n) || dalloc(&dSlots, n)) return 1;
+        std::string e2;
+        eval = make_evaluator(cfg, G::H, G::W, G::C, G::A, &e2);
+        if (!eval && cfg.evaluator != GAZ_EVAL_EXTERNAL) return fail("evaluator: " + e2);
+        GAZ_LAUNCH(k_init_games<G>, n, WAVE, stream, E, 0);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int check_device_error() {
+        int32_t code = 0;
+        HIP_OK(hipMemcpy(&code, E.error, sizeof(code), hipMemcpyDeviceToHost));
+        if (code) {
+            const char* names[] = {"", "tree arena full (raise nodes_per_tree)", "root not fully expanded at move end",
+                                   "selection path longer than PATH_CAP", "state-machine loop guard", "PUCT picked an un-poppable child"};
+            return fail(std::string("device error: ") + (code > 0 && code < 6 ? names[code] : "unknown"));
+        }
+        return 0;
+    }
+
+    int load_weights(const gaz_tensor* t, int n) override {
+        if (!eval) return fail("no evaluator to load weights into");
+        std::string m;
+        if (eval->load(t, n, stream, &m)) return fail("load_weights: " + m);
+        return 0;
+    }
+
+    int reset_games(const int32_t* slots, int n) override {
+        if (slots) {
+            if (n > E.n_games) return fail("reset_games: too many slots");
+            HIP_OK(hipMemcpyAsync(dSlots, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
+            GAZ_LAUNCH(k_reset_games<G>, n, WAVE, stream, E, (const int32_t*)dSlots, n);
+        } else {
+            GAZ_LAUNCH(k_reset_games<G>, E.n_games, WAVE, stream, E, (const int32_t*)nullptr, E.n_games);
+        }
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+
+    hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
+
+    int one_wave(bool with_eval) {
+        hipEvent_t e0 = 0, e1 = 0, e2 = 0;
+        if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
+        GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+        if (timing) hipEventRecord(e1, stream);
+        if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
+        if (timing) hipEventRecord(e2, stream);
+        n_waves_total++;
+        return 0;
+    }
+
+    int counts(int32_t out[8]) {
+        HIP_OK(hipMemsetAsync(dCount, 0, 8 * sizeof(int32_t), stream));
+        GAZ_LAUNCH(k_count<G>, E.n_games, WAVE, stream, E, dCount);
+        HIP_OK(hipMemcpyAsync(out, dCount, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int run_move(int32_t* n_waiting) override {
+        if (!E.sync_moves) return fail("run_move needs sync_moves = 1");
+        if (!eval) return fail("run_move needs a built-in evaluator (use wave_begin/wave_end with GAZ_EVAL_EXTERNAL)");
+        // a move needs at most iter_limit + 2 evaluations (both roots); poll the device every 16 waves
+        const int max_waves = (E.run_iterations < 3 * G::A ? 3 * G::A : E.run_iterations) + 8;
+        int32_t c[8];
+        for (int w = 0; w < max_waves + 16; w += 16) {
+            for (int i = 0; i < 16; ++i) one_wave(true);
+            if (counts(c)) return 1;
+            if (check_device_error()) return 1;
+            if (c[0] == 0) break;
+        }
+        if (c[0] != 0) return fail("run_move: games still searching after the wave budget");
+        if (n_waiting) *n_waiting = E.n_games;
+        return 0;
+    }
+
+    int get_root_stats(uint32_t* oN, float* oW, float* oP, float* oPol, uint32_t* oRV, float* oQ, int32_t* oChosen,
+                       int32_t* oPhase) override {
+        GAZ_LAUNCH(k_gather_root<G>, E.n_games, WAVE, stream, E, dN, dW, dP, dPol, dRV, dQ, dChosen, dPhase, dPending);
+        HIP_OK(hipGetLastError());
+        const size_t na = (size_t)E.n_games * G::A, n = E.n_games;
+        if (oN) HIP_OK(hipMemcpyAsync(oN, dN, na * 4, hipMemcpyDeviceToHost, stream));
+        if (oW) HIP_OK(hipMemcpyAsync(oW, dW, na * 4, hipMemcpyDeviceToHost, stream));
+        if (oP) HIP_OK(hipMemcpyAsync(oP, dP, na * 4, hipMemcpyDeviceToHost, stream));
+        if (oPol) HIP_OK(hipMemcpyAsync(oPol, dPol, na * 4, hipMemcpyDeviceToHost, stream));
+        if (oRV) HIP_OK(hipMemcpyAsync(oRV, dRV, n * 4, hipMemcpyDeviceToHost, stream));
+        if (oQ) HIP_OK(hipMemcpyAsync(oQ, dQ, n * 4, hipMemcpyDeviceToHost, stream));
+        if (oChosen) HIP_OK(hipMemcpyAsync(oChosen, dChosen, n * 4, hipMemcpyDeviceToHost, stream));
+        if (oPhase) HIP_OK(hipMemcpyAsync(oPhase, dPhase, n * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int apply_moves(const int32_t* moves) override {
+        if (!E.sync_moves) return fail("apply_moves needs sync_moves = 1");
+        if (moves) HIP_OK(hipMemcpyAsync(dMoves, moves, sizeof(int32_t) * E.n_games, hipMemcpyHostToDevice, stream));
+        GAZ_LAUNCH(k_release<G>, E.n_games, WAVE, stream, E, moves ? (const int32_t*)dMoves : (const int32_t*)nullptr);
+        HIP_OK(hipGetLastError());
+        // run the APPLY phase (do_action, win check, prune) up to the next evaluation request
+        GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+        if (eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, false);
+        HIP_OK(hipGetLastError());
+        return check_device_error();
+    }
+
+    int run_waves(int n) override {
+        if (!eval) return fail("run_waves needs a built-in evaluator");
+        for (int i = 0; i < n; ++i) one_wave(true);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+
+    int wave_begin() override { one_wave(false); HIP_OK(hipGetLastError()); return 0; }
+    int wave_end() override { return 0; }   // the next wave_begin consumes the outputs; nothing to do here
+
+    int batch_ptrs(void** a, void** b, void** c) override {
+        if (a) *a = E.nn_in; if (b) *b = E.nn_policy; if (c) *c = E.nn_value; return 0;
+    }
+    int read_batch(int8_t* inputs, int32_t* pending) override {
+        if (inputs) HIP_OK(hipMemcpyAsync(inputs, E.nn_in, (size_t)E.n_games * G::HW * G::C, hipMemcpyDeviceToHost, stream));
+        if (pending) {
+            GAZ_LAUNCH(k_gather_root<G>, E.n_games, WAVE, stream, E, dN, dW, dP, dPol, dRV, dQ, dChosen, dPhase, dPending);
+            HIP_OK(hipMemcpyAsync(pending, dPending, (size_t)E.n_games * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+        return check_device_error();
+    }
+    int write_outputs(const float* policy, const float* value) override {
+        HIP_OK(hipMemcpyAsync(E.nn_policy, policy, (size_t)E.n_games * G::A * 4, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(E.nn_value, value, (size_t)E.n_games * 4, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int record_layout(gaz_record_layout* o) override {
+        o->record_bytes = RL::SIZE; o->max_T = G::MAXT; o->A = G::A; o->t_pad = G::TPAD;
+        o->off_hdr = RL::OFF_HDR; o->off_actions = RL::OFF_ACT; o->off_q = RL::OFF_Q; o->off_root_visits = RL::OFF_RV;
+        o->off_evals = RL::OFF_EV; o->off_policy = RL::OFF_POL; o->off_N = RL::OFF_N; o->off_W = RL::OFF_W; o->off_P = RL::OFF_P;
+        return 0;
+    }
+
+    int drain(void* out, int max_records, int32_t* n_out) override {
+        *n_out = 0;
+        if (E.ring_cap <= 0) return 0;
+        HIP_OK(hipStreamSynchronize(stream));
+        uint32_t head[2];
+        HIP_OK(hipMemcpy(head, E.ring_head, sizeof(head), hipMemcpyDeviceToHost));
+        uint32_t avail = head[0] - ring_consumed;
+        if ((int)avail > max_records) avail = (uint32_t)max_records;
+        for (uint32_t i = 0; i < avail; ++i) {
+            const uint32_t slot = (ring_consumed + i) % (uint32_t)E.ring_cap;
+            HIP_OK(hipMemcpy((uint8_t*)out + (size_t)i * RL::SIZE, E.ring + (size_t)slot * RL::SIZE, RL::SIZE, hipMemcpyDeviceToHost));
+        }
+        ring_consumed += avail;
+        HIP_OK(hipMemcpy(E.ring_head + 1, &ring_consumed, sizeof(uint32_t), hipMemcpyHostToDevice));
+        *n_out = (int32_t)avail;
+        return check_device_error();
+    }
+
+    int get_stats(uint64_t out[8]) override {
+        int32_t c[8];
+        if (counts(c)) return 1;
+        unsigned long long s[8];
+        HIP_OK(hipMemcpy(s, E.stats, sizeof(s), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 6; ++i) out[i] = s[i];
+        memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8);
+        return check_device_error();
+    }
+
+    int synchronize() override { HIP_OK(hipStreamSynchronize(stream)); return check_device_error(); }
+
+    int timing_reset(int enable) override {
+        HIP_OK(hipStreamSynchronize(stream));
+        for (hipEvent_t e : ev) hipEventDestroy(e);
+        ev.clear(); n_waves_total = 0; timing = enable != 0;
+        if (eval) eval->timing_reset();
+        return 0;
+    }
+    int timing_get(double* ms_tree, double* ms_eval, double* ms_dom, int64_t* n_dom, int64_t* n_waves) override {
+        HIP_OK(hipStreamSynchronize(stream));
+        double t = 0, e = 0;
+        for (size_t i = 0; i + 2 < ev.size(); i += 3) {
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, ev[i], ev[i + 1]); hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]);
+            t += a; e += b;
+        }
+        if (ms_tree) *ms_tree = t; if (ms_eval) *ms_eval = e;
+        double d = 0; int64_t nd = 0;
+        if (eval) eval->timing_get(&d, &nd);
+        if (ms_dom) *ms_dom = d; if (n_dom) *n_dom = nd; if (n_waves) *n_waves = n_waves_total;
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int gaz_engine_create(const gaz_engine_config* cfg, gaz_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return 1; }
+    gaz_engine* h = nullptr;
+    switch (cfg->game) {
+        case GAZ_GAME_TICTACTOE: h = new EngineT<Game<GAME_TTT>>(); break;
+        case GAZ_GAME_CONNECT4: h = new EngineT<Game<GAME_C4>>(); break;
+        case GAZ_GAME_GOMOKU: h = new EngineT<Game<GAME_GMK>>(); break;
+        default: g_create_error = "unknown game id"; return 1;
+    }
+    h->cfg = *cfg;
+    if (h->init()) { g_create_error = h->err; delete h; *out = nullptr; return 1; }
+    *out = h;
+    return 0;
+}
+void gaz_engine_destroy(gaz_engine* h) { delete h; }
+const char* gaz_engine_last_error(gaz_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int gaz_engine_load_weights(gaz_engine* h, const gaz_tensor* t, int32_t n) { return h->load_weights(t, n); }
+int gaz_engine_reset_games(gaz_engine* h, const int32_t* slots, int32_t n) { return h->reset_games(slots, n); }
+int gaz_engine_run_move(gaz_engine* h, int32_t* n_waiting) { return h->run_move(n_waiting); }
+int gaz_engine_get_root_stats(gaz_engine* h, uint32_t* N, float* W, float* P, float* pol, uint32_t* rv, float* q, int32_t* chosen,
+                              int32_t* phase) { return h->get_root_stats(N, W, P, pol, rv, q, chosen, phase); }
+int gaz_engine_apply_moves(gaz_engine* h, const int32_t* moves) { return h->apply_moves(moves); }
+int gaz_engine_run_waves(gaz_engine* h, int32_t n) { return h->run_waves(n); }
+int gaz_engine_wave_begin(gaz_engine* h) { return h->wave_begin(); }
+int gaz_engine_wave_end(gaz_engine* h) { return h->wave_end(); }
+int gaz_engine_batch_ptrs(gaz_engine* h, void** a, void** b, void** c) { return h->batch_ptrs(a, b, c); }
+int gaz_engine_read_batch(gaz_engine* h, int8_t* in, int32_t* pending) { return h->read_batch(in, pending); }
+int gaz_engine_write_outputs(gaz_engine* h, const float* p, const float* v) { return h->write_outputs(p, v); }
+int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* o) { return h->record_layout(o); }
+int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out) { return h->drain(out, max_records, n_out); }
+int gaz_engine_get_stats(gaz_engine* h, uint64_t out[8]) { return h->get_stats(out); }
+int gaz_engine_synchronize(gaz_engine* h) { return h->synchronize(); }
+int gaz_engine_timing_reset(gaz_engine* h, int32_t enable) { return h->timing_reset(enable); }
+int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }
+
+}  // extern "C"

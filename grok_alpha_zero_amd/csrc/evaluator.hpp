@@ -1,0 +1,74 @@
+// evaluator.hpp — the batched policy/value evaluator behind the wave kernel.
+//
+// Replaces the reference's session.run round trip (MCTS.py:224-235 -> Client_Server.py:28-55 ->
+// Client_Server.Server.start :162-217 -> onnxruntime): the wave kernel has already written every game's
+// encoded leaf state as row g of `in` (int8 [n][H*W*C]); forward() fills policy f32 [n][A] and value f32 [n]
+// on the same stream.  Rows are independent: a row's outputs never depend on which other rows are in the
+// batch (required for bit-reproducible search).
+#pragma once
+#include <string>
+#include "../../include/gaz_engine.h"
+#include "rt.hpp"
+
+namespace gaz {
+
+struct Evaluator {
+    virtual ~Evaluator() {}
+    virtual int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) { (void)t; (void)n; (void)s; (void)err; return 0; }
+    virtual void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) = 0;
+    virtual void timing_reset() {}
+    virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
+};
+
+// synthetic evaluator for parity tests: outputs are exact float32 functions of a hash of the input row
+//   policy[a] = ((h_a >> 8) + 1) * 2^-24,  value = (h_v >> 8) * 2^-23 - 1,  h = fmix32(FNV-1a(row, salt ^ x))
+GAZ_DEV uint32_t hash_row(const int8_t* s, int n, uint32_t seed) {
+    uint32_t h = 2166136261u ^ seed;
+    for (int i = 0; i < n; ++i) { h ^= (uint8_t)s[i]; h *= 16777619u; }
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+template <int UNUSED> GAZ_KERNEL k_hash_eval(const int8_t* in, float* policy, float* value, int n, int row_bytes, int A, uint32_t salt) {
+#ifdef GAZ_HOST_EMU
+    const int first = block_id(), step = 1 << 30;
+#else
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+#endif
+    for (int idx = first; idx < n * (A + 1); idx += step) {
+        const int g = idx / (A + 1), a = idx % (A + 1);
+        const int8_t* row = in + (size_t)g * row_bytes;
+        if (a < A) {
+            uint32_t h = hash_row(row, row_bytes, salt ^ ((uint32_t)(a + 1) * 0x9E3779B1u));
+            policy[(size_t)g * A + a] = (float)((h >> 8) + 1u) * (1.0f / 16777216.0f);
+        } else {
+            uint32_t h = hash_row(row, row_bytes, salt ^ 0x51ED270Bu);
+            value[g] = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        }
+    }
+}
+
+struct HashEvaluator : Evaluator {
+    int row_bytes, A; uint32_t salt;
+    HashEvaluator(int rb, int a, uint32_t s) : row_bytes(rb), A(a), salt(s) {}
+    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool) override {
+        const int total = n * (A + 1);
+#ifdef GAZ_HOST_EMU
+        GAZ_LAUNCH(k_hash_eval<0>, total, 1, s, in, policy, value, n, row_bytes, A, salt);
+#else
+        GAZ_LAUNCH(k_hash_eval<0>, (total + 255) / 256, 256, s, in, policy, value, n, row_bytes, A, salt);
+#endif
+    }
+};
+
+Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err);
+
+inline Evaluator* make_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err) {
+    if (cfg.evaluator == GAZ_EVAL_HASH) return new HashEvaluator(H * W * C, A, cfg.hash_salt);
+    if (cfg.evaluator == GAZ_EVAL_RESNET) return make_resnet_evaluator(cfg, H, W, C, A, err);
+    if (cfg.evaluator == GAZ_EVAL_EXTERNAL) return nullptr;
+    *err = "unknown evaluator id";
+    return nullptr;
+}
+
+}  // namespace gaz

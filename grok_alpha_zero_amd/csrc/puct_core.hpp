@@ -1,0 +1,700 @@
+// puct_core.hpp — the PUCT self-play wave kernel: select / expand / backup, Dirichlet noise, move
+// sampling, re-rooting and the Self_Play per-game state machine, one wavefront per game.
+//
+// Reference path replaced (all file:line under /root/reference):
+//   MCTS._get_best_PUCT_score_index  MCTS.py:172-191   -> best_puct_slot()       (K1)
+//   MCTS._PUCT_select                MCTS.py:193-222   -> puct_select()          (K2)
+//   MCTS.get_terminal_actions_fn     MCTS.py:247-294   -> terminal_probe()       (K3)
+//   MCTS._expand                     MCTS.py:434-511   -> expand_pre()/expand_post() around the batched evaluator (K4,K8,K9)
+//   MCTS._expand_with_terminal_actions MCTS.py:367-428 -> make_terminal_parent() (K5)
+//   MCTS._back_propagate             MCTS.py:513-526   -> backup()               (K6)
+//   MCTS._apply_dirichlet            MCTS.py:243-245   -> make_priors()          (K7)
+//   MCTS.create_expand_root          MCTS.py:296-365   -> root_pre()/root_post() (K12)
+//   MCTS.run                         MCTS.py:528-618   -> PH_MOVE_BEGIN/PH_SIMS/PH_MOVE_END (K10)
+//   MCTS._set_root / prune_tree      MCTS.py:620-671   -> prune()                (K11)
+//   Self_Play.__init__ / play        Self_Play.py:37-57,71-157 -> game_step() phases
+//   Client_Server.Parallelized_Session/Server (Client_Server.py:10-217) -> deleted: expand_pre writes the
+//   leaf's encoded state straight into row g of the wave's evaluator batch in HBM.
+//
+// One simulation per game is in flight (the reference has no virtual loss), so a "wave" is: every game
+// runs tree-only simulations until it needs an evaluation, writes its leaf into the batch and stops; one
+// forward pass evaluates all G leaves; the next launch first consumes the result (expand_post + backup)
+// and carries on.  Tree updates need no atomics.
+#pragma once
+#include "det.hpp"
+#include "tree.hpp"
+
+namespace gaz {
+
+constexpr int PATH_CAP = 256;
+
+struct PathEnt { int32_t node; int32_t slot; };
+
+template <class G> struct DevParams {
+    // configuration
+    int32_t n_games, run_iterations, max_actions, explore_first, explore_second;
+    int32_t create_new_root, sync_moves, nodes_per_tree, ring_cap, use_dirichlet;
+    double c_init, c_base, alpha, eps;
+    float one_minus_eps;
+    uint32_t key0, key1, slot_offset;
+    // state in HBM
+    uint8_t* arena;            // [n_games][2][nodes_per_tree][NodeLayout::SIZE]
+    TreeState* trees;          // [n_games][2]
+    GameState<G>* games;       // [n_games]
+    PathEnt* paths;            // [n_games][PATH_CAP] path of the pending expansion (root -> leaf edge list)
+    uint8_t* recs;             // [n_games][RecLayout::SIZE] game in progress
+    uint8_t* ring;             // [ring_cap][RecLayout::SIZE] finished games
+    uint32_t* ring_head;       // [2]: produced, consumed
+    // evaluator batch, row g = game g
+    int8_t* nn_in;             // [n_games][HW*C]
+    float* nn_policy;          // [n_games][A]
+    float* nn_value;           // [n_games]
+    unsigned long long* stats; // [8]: game_stats[0..5] (Self_Play.py:181-188), [6] waves, [7] spare
+    int32_t* error;            // first error code, 0 = none
+};
+
+enum : int32_t { ERR_ARENA_FULL = 1, ERR_ROOT_NOT_EXPANDED = 2, ERR_PATH_OVERFLOW = 3, ERR_LOOP_GUARD = 4, ERR_BAD_SELECT = 5 };
+
+template <class G> struct Scratch {   // per-wave LDS
+    int8_t board[G::BPAD];
+    uint8_t legal[G::APAD];
+    uint8_t tact[G::APAD];     // terminal actions, wins first
+    uint8_t twin[G::APAD];     // 1 = win, 0 = draw
+    uint8_t sact[G::APAD];     // sorted actions
+    float pri[G::APAD];
+    float spri[G::APAD];
+    double gam[G::APAD];
+    PathEnt path[PATH_CAP];
+};
+
+template <class T> GAZ_DEV T uni(T v) {
+#ifdef GAZ_HOST_EMU
+    return v;
+#else
+    return (T)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+template <class G> GAZ_DEV NodeRef<G> node_at(const DevParams<G>& E, int g, int t, int idx) {
+    size_t off = (((size_t)g * 2 + t) * (size_t)E.nodes_per_tree + (size_t)idx) * (size_t)NodeLayout<G>::SIZE;
+    return NodeRef<G>{E.arena + off};
+}
+
+GAZ_DEV void set_error(int32_t* err, int32_t code) {
+    if (lane_id() == 0 && *err == 0) *err = code;
+}
+
+template <class G> GAZ_DEV det::Event make_event(const DevParams<G>& E, int g, const GameState<G>& gs, TreeState& ts,
+                                                 int tree, uint32_t purpose) {
+    det::Event e;
+    e.key0 = E.key0; e.key1 = E.key1; e.slot = E.slot_offset + (uint32_t)g; e.game_seq = gs.game_seq;
+    e.event = ts.event; e.tree = (uint32_t)tree; e.purpose = purpose;
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// legal actions of a board in ascending action order -> S.legal; returns count.  Lanes test cells,
+// ballot + prefix popcount compacts (Connect4.py:271-276, Gomoku.py:114-119, Tictactoe.py:186-187).
+template <class G> GAZ_DEV int build_legal(const int8_t* board, uint8_t* out) {
+    int n = 0;
+    for (int base = 0; base < G::A; base += WAVE) {
+        int a = base + lane_id();
+        bool ok = (a < G::A) && action_legal<G>(board, a);
+        uint64_t m = ballot(ok);
+        if (ok) out[n + popcll(m & ((1ull << lane_id()) - 1ull))] = (uint8_t)a;
+        n += popcll(m);
+    }
+    wave_sync();
+    return n;
+}
+
+template <class G> GAZ_DEV int count_empty(const int8_t* board) {
+    int n = 0;
+    for (int base = 0; base < G::HW; base += WAVE) {
+        int c = base + lane_id();
+        n += popcll(ballot(c < G::HW && board[c] == 0));
+    }
+    return n;
+}
+
+// K3: which legal actions end the game for `player`?  One lane per candidate; result list is ordered the
+// way the reference orders it: stable ascending argsort of the 0/1 mask, reversed (MCTS.py:293-294 with the
+// documented tie rule) = wins in DESCENDING candidate order, then draws in descending candidate order.
+template <class G> GAZ_DEV int terminal_probe(const int8_t* board, const uint8_t* legal, int n_legal, int player,
+                                              uint8_t* tact, uint8_t* twin, bool& any_win) {
+    const int empties = G::DRAWS ? count_empty<G>(board) : 0;
+    int nt = 0;
+    // pass 1: wins (descending), pass 2: draws (descending)
+    any_win = false;
+    for (int pass = 0; pass < (G::DRAWS ? 2 : 1); ++pass) {
+        for (int base = ((n_legal - 1) / WAVE) * WAVE; base >= 0; base -= WAVE) {
+            int i = base + lane_id();
+            bool hit = false;
+            if (i < n_legal) {
+                int a = legal[i];
+                bool win = wins_after<G>(board, landing_cell<G>(board, a), player);
+                hit = (pass == 0) ? win : (!win && empties == 1);
+            }
+            uint64_t m = ballot(hit);
+            if (hit) {
+                int higher = popcll(m >> lane_id()) - 1;   // hits in higher lanes come first
+                tact[nt + higher] = legal[i];
+                twin[nt + higher] = (pass == 0) ? 1 : 0;
+            }
+            nt += popcll(m);
+        }
+        if (pass == 0) any_win = nt > 0;
+    }
+    wave_sync();
+    return nt;
+}
+
+// get_input_state_MCTS -> int8 [HW][C] row of the evaluator batch.
+// Connect4.py:329-346 (incl. the plane-0 overwrite once >= 4 moves were played), Gomoku.py:175-177,
+// Tictactoe.py:231-235.  hist3 = last three actions newest first, n_hist = len(action_history).
+template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_player, const uint8_t* hist3, int n_hist,
+                                             int8_t* out) {
+    if (G::ID == GAME_C4) {
+        int max_length = n_hist - 1; if (max_length > 3) max_length = 3; if (max_length < 0) max_length = 0;
+        int rem[3] = {-1, -1, -1};
+        for (int i = 0; i < max_length; ++i) {      // y = min(where(prev_board[:, x] != 0)), then clear it
+            int x = hist3[i];
+            int y = 0;
+            for (; y < 6; ++y) {
+                int c = y * 7 + x;
+                if (board[c] != 0 && c != rem[0] && c != rem[1] && c != rem[2]) break;
+            }
+            rem[i] = y * 7 + x;
+        }
+        for (int c = lane_id(); c < G::HW; c += WAVE) {
+            int8_t b = board[c];
+            int8_t p2 = (c == rem[0]) ? 0 : b;
+            int8_t p1 = (c == rem[0] || c == rem[1]) ? 0 : b;
+            int8_t p0 = (max_length >= 3) ? ((c == rem[0] || c == rem[1] || c == rem[2]) ? (int8_t)0 : b)
+                                          : (int8_t)current_player;
+            if (max_length < 1) p2 = 0;
+            if (max_length < 2) p1 = 0;
+            char4 v; v.x = p0; v.y = p1; v.z = p2; v.w = b;
+            *reinterpret_cast<char4*>(out + c * 4) = v;
+        }
+    } else {
+        for (int c = lane_id(); c < G::HW; c += WAVE) {
+            out[c * 2] = (int8_t)(-current_player);
+            out[c * 2 + 1] = board[c];
+        }
+    }
+}
+
+// K1: argmax_i  Q_i + U_i over the node's n_actions children (expanded and not), float64 like numpy:
+//   U_i = (P_i * (sqrt(Np) / (N_i + 1))) * (c_init + ln((Np + c_base + 1) / c_base));  Q_i = f32(W_i / N_i) or W_i
+template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_actions, uint64_t parent_visits,
+                                              double c_init, double c_base) {
+    const double pv = (double)parent_visits;
+    const double s = dsqrt(pv);
+    const double c = c_init + det::dlog((pv + c_base + 1.0) / c_base);
+    const uint32_t* N = nd.N(); const float* Wv = nd.W(); const float* P = nd.P();
+    double best = 0.0; int bi = 0x7fffffff;
+    for (int i = lane_id(); i < n_actions; i += WAVE) {
+        uint32_t n = N[i]; float w = Wv[i];
+        double u = ((double)P[i] * (s / (double)(n + 1u))) * c;
+        float q = w;
+        if (n > 0) q = (float)((double)w / (double)n);
+        double sc = (double)q + u;
+        if (bi == 0x7fffffff || sc > best) { best = sc; bi = i; }
+    }
+    wave_argmax(best, bi);
+    return uni(bi);
+}
+
+// K8 + K7 + K9: gather legal policy entries, renormalise (numpy pairwise float32 sum), mix Dirichlet noise,
+// sort descending (ties: higher original index first) into S.sact / S.spri.
+template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const GameState<G>& gs, TreeState& ts, int tree,
+                                            Scratch<G>& S, const float* policy, int n_legal) {
+    for (int i = lane_id(); i < n_legal; i += WAVE) S.pri[i] = policy[S.legal[i]];
+    wave_sync();
+    const float sum = det::np_pairwise_sum<float>(S.pri, n_legal);   // uniform: every lane computes the same value
+    wave_sync();
+    if (E.use_dirichlet) {
+        det::Event e = make_event(E, g, gs, ts, tree, det::P_DIRICHLET);
+        for (int i = lane_id(); i < n_legal; i += WAVE) S.gam[i] = det::gamma(e, (uint32_t)i, E.alpha);
+        wave_sync();
+        double gs_sum = 0.0;
+        for (int i = 0; i < n_legal; ++i) gs_sum = gs_sum + S.gam[i];    // sequential, same in every lane
+        for (int i = lane_id(); i < n_legal; i += WAVE) {
+            float p = S.pri[i] / sum;
+            float a = E.one_minus_eps * p;
+            S.pri[i] = (float)((double)a + E.eps * (S.gam[i] / gs_sum));
+        }
+        if (lane_id() == 0) ts.event += 1;
+    } else {
+        for (int i = lane_id(); i < n_legal; i += WAVE) S.pri[i] = S.pri[i] / sum;
+    }
+    wave_sync();
+    for (int i = lane_id(); i < n_legal; i += WAVE) {     // rank sort
+        float v = S.pri[i]; int rank = 0;
+        for (int j = 0; j < n_legal; ++j) { float o = S.pri[j]; rank += (o > v) || (o == v && j > i); }
+        S.sact[rank] = S.legal[i]; S.spri[rank] = v;
+    }
+    wave_sync();
+}
+
+template <class G> GAZ_DEV void write_children_from_scratch(const NodeRef<G>& nd, const Scratch<G>& S, int n) {
+    for (int i = lane_id(); i < n; i += WAVE) {
+        nd.N()[i] = 0u; nd.W()[i] = 0.0f; nd.P()[i] = S.spri[i]; nd.child()[i] = CHILD_NONE; nd.act()[i] = S.sact[i];
+    }
+}
+
+template <class G> GAZ_DEV void copy_board(int8_t* dst, const int8_t* src) {
+    for (int c = lane_id(); c < G::BPAD; c += WAVE) dst[c] = src[c];
+}
+
+// K6: add (value, visits) along the recorded path, sign alternating upward from the leaf edge.
+template <class G> GAZ_DEV void backup(const DevParams<G>& E, int g, int t, TreeState& ts, const PathEnt* path, int depth,
+                                       float value, uint32_t visits) {
+    for (int d = lane_id(); d < depth; d += WAVE) {
+        NodeRef<G> nd = node_at(E, g, t, path[d].node);
+        float v = ((depth - 1 - d) & 1) ? -value : value;
+        int s = path[d].slot;
+        nd.W()[s] = nd.W()[s] + v;
+        nd.N()[s] = nd.N()[s] + visits;
+    }
+    if (lane_id() == 0) ts.root_visits += visits;
+    wave_sync();
+}
+
+// terminal parent / terminal root record (K5 and the terminal branch of K12)
+template <class G> GAZ_DEV void write_terminal_children(const NodeRef<G>& nd, const Scratch<G>& S, int nt, bool any_win,
+                                                        bool as_root) {
+    for (int i = lane_id(); i < nt; i += WAVE) {
+        float mask = S.twin[i] ? 1.0f : 0.0f;
+        nd.N()[i] = 1u;
+        // K5: child_values = terminal_mask (MCTS.py:398); K12: every child backed up with value = any_win (MCTS.py:316-344)
+        nd.W()[i] = as_root ? (any_win ? 1.0f : 0.0f) : mask;
+        nd.P()[i] = any_win ? mask / (float)nt : 1.0f / (float)nt;     // MCTS.py:376-382 / 318-321
+        nd.child()[i] = S.twin[i] ? CHILD_LEAF_WIN : CHILD_LEAF_DRAW;
+        nd.act()[i] = S.tact[i];
+    }
+}
+
+template <class G> GAZ_DEV int alloc_node(const DevParams<G>& E, TreeState& ts) {
+    int idx = (int)ts.n_nodes;
+    if (idx >= E.nodes_per_tree) { set_error(E.error, ERR_ARENA_FULL); return -1; }
+    wave_sync();
+    if (lane_id() == 0) ts.n_nodes = (uint32_t)idx + 1u;
+    wave_sync();
+    return idx;
+}
+
+// K12 first half: create_expand_root for tree t at the game's current position.  Returns true when the
+// root needs an evaluation (input row written), false when it was completed here (terminal root).
+template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+    if (lane_id() == 0) { ts.n_nodes = 0; ts.root = -1; ts.root_visits = 0; }
+    wave_sync();
+    copy_board<G>(S.board, gs.board);
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    bool any_win;
+    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win);
+    uint8_t h3[3];
+    for (int i = 0; i < 3; ++i) h3[i] = (gs.n_hist - 1 - i >= 0) ? gs.hist[gs.n_hist - 1 - i] : 0;
+    const int idx = alloc_node(E, ts);
+    if (idx < 0) return false;
+    NodeRef<G> nd = node_at(E, g, t, idx);
+    if (lane_id() == 0) {
+        NodeHdr h; memset(&h, 0, sizeof(h));
+        h.parent = -1; h.slot = 0; h.player = (int8_t)(-gs.next_player); h.n_hist = (uint16_t)gs.n_hist;
+        h.hist3[0] = h3[0]; h.hist3[1] = h3[1]; h.hist3[2] = h3[2]; h.action = h3[0];
+        if (nt > 0) { h.n_actions = (uint8_t)nt; h.n_children = (uint8_t)nt; h.flags = NF_TERMINAL_PARENT; }
+        *nd.hdr() = h;
+        ts.root = idx;
+    }
+    copy_board<G>(nd.board(), S.board);
+    if (nt > 0) {
+        write_terminal_children<G>(nd, S, nt, any_win, true);
+        if (lane_id() == 0) ts.root_visits = (uint64_t)nt;     // one backup per terminal child (MCTS.py:344)
+        wave_sync();
+        return false;
+    }
+    encode_input<G>(S.board, -gs.next_player, h3, gs.n_hist, E.nn_in + (size_t)g * (G::HW * G::C));
+    wave_sync();
+    return true;
+}
+
+// K12 second half: the evaluator's policy row -> root priors (the value is discarded, MCTS.py:346-365)
+template <class G> GAZ_DEV void root_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+    NodeRef<G> nd = node_at(E, g, t, ts.root);
+    copy_board<G>(S.board, nd.board());
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    make_priors<G>(E, g, gs, ts, t, S, E.nn_policy + (size_t)g * G::A, n_legal);
+    write_children_from_scratch<G>(nd, S, n_legal);
+    if (lane_id() == 0) { nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0; }
+    wave_sync();
+}
+
+// K2: descend from the root.  Returns 0 = expand `node` (its next un-popped child), 1 = terminal leaf hit
+// (value in leaf_win).  S.path receives the edge list root..selected, depth its length.
+template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
+                                           int& node, int& depth, bool& leaf_win) {
+    node = ts.root; depth = 0;
+    uint64_t pv = ts.root_visits;
+    for (;;) {
+        NodeRef<G> nd = node_at(E, g, t, node);
+        const NodeHdr h = *nd.hdr();
+        const int n_actions = uni((int)h.n_actions), n_children = uni((int)h.n_children);
+        if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return -1; }
+        if (uni((int)h.flags) & NF_TERMINAL_PARENT) {           // MCTS.py:200-208
+            // np.sum(child_values) > 0  <=>  some child has W > 0 (all W >= 0 here)
+            uint64_t winmask_any = 0; int n_win = 0;
+            for (int base = 0; base < n_children; base += WAVE) {
+                int i = base + lane_id();
+                bool pos = (i < n_children) && nd.W()[i] > 0.0f;
+                winmask_any |= ballot(pos);
+                n_win += popcll(ballot((i < n_children) && nd.child()[i] == CHILD_LEAF_WIN));
+            }
+            const bool wins_only = winmask_any != 0;
+            const int n_cand = wins_only ? n_win : n_children;
+            det::Event e = make_event(E, g, gs, ts, t, det::P_TERMINAL_PICK);
+            const int k = (int)det::pick(e, (uint32_t)n_cand);
+            if (lane_id() == 0) ts.event += 1;
+            // k-th candidate in child order
+            int slot = -1, seen = 0;
+            for (int base = 0; base < n_children && slot < 0; base += WAVE) {
+                int i = base + lane_id();
+                bool c = (i < n_children) && (!wins_only || nd.child()[i] == CHILD_LEAF_WIN);
+                uint64_t m = ballot(c);
+                int cnt = popcll(m);
+                if (k < seen + cnt) {
+                    int want = k - seen;       // want-th set bit of m
+                    uint64_t mm = m;
+                    for (int q = 0; q < want; ++q) mm &= mm - 1;
+                    slot = base + ffsll0(mm);
+                }
+                seen += cnt;
+            }
+            S.path[depth].node = node; S.path[depth].slot = slot; depth++;
+            leaf_win = uni(nd.child()[slot]) == CHILD_LEAF_WIN;
+            wave_sync();
+            return 1;
+        }
+        const int best = best_puct_slot<G>(nd, n_actions, pv, E.c_init, E.c_base);
+        if (best == n_children) { wave_sync(); return 0; }          // MCTS.py:217-218
+        if (best > n_children) { set_error(E.error, ERR_BAD_SELECT); return -1; }
+        S.path[depth].node = node; S.path[depth].slot = best; depth++;
+        pv = uni(nd.N()[best]);
+        node = uni(nd.child()[best]);
+    }
+}
+
+// K4 first half (+K3, K5): expand the next child of `node`.  Returns true if an evaluation is pending
+// (row g written), false if the simulation completed here (terminal parent created and backed up).
+template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
+                                           int node, int depth) {
+    NodeRef<G> pn = node_at(E, g, t, node);
+    const NodeHdr ph = *pn.hdr();
+    const int slot = uni((int)ph.n_children);
+    const int action = uni((int)pn.act()[slot]);                       // popleft (MCTS.py:437)
+    const int mover = -(int)uni((int)ph.player);
+    copy_board<G>(S.board, pn.board());
+    wave_sync();
+    const int cell = landing_cell<G>(S.board, action);
+    wave_sync();
+    if (lane_id() == 0) S.board[cell] = (int8_t)mover;                 // do_action_MCTS (MCTS.py:441)
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    bool any_win;
+    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win);
+    const int idx = alloc_node(E, ts);
+    if (idx < 0) return false;
+    NodeRef<G> nd = node_at(E, g, t, idx);
+    if (lane_id() == 0) {
+        NodeHdr h; memset(&h, 0, sizeof(h));
+        h.parent = node; h.slot = (int16_t)slot; h.player = (int8_t)mover; h.n_hist = (uint16_t)(ph.n_hist + 1);
+        h.hist3[0] = (uint8_t)action; h.hist3[1] = ph.hist3[0]; h.hist3[2] = ph.hist3[1]; h.action = (uint8_t)action;
+        if (nt > 0) { h.n_actions = (uint8_t)nt; h.n_children = (uint8_t)nt; h.flags = NF_TERMINAL_PARENT; }
+        *nd.hdr() = h;
+    }
+    S.path[depth].node = node; S.path[depth].slot = slot;
+    wave_sync();
+    if (nt > 0) {                                                      // K5, MCTS.py:367-428
+        write_terminal_children<G>(nd, S, nt, any_win, false);
+        if (lane_id() == 0) { pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1); }
+        wave_sync();
+        // value = -(len(terminal_mask)) if any win else 0; visits = len(terminal_mask)  (MCTS.py:373-380, 428)
+        backup<G>(E, g, t, ts, S.path, depth + 1, any_win ? -(float)nt : 0.0f, (uint32_t)nt);
+        return false;
+    }
+    copy_board<G>(nd.board(), S.board);
+    uint8_t h3[3] = {(uint8_t)action, ph.hist3[0], ph.hist3[1]};
+    encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
+    // park the path for expand_post
+    PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    for (int d = lane_id(); d <= depth; d += WAVE) gp[d] = S.path[d];
+    if (lane_id() == 0) {
+        gs.pend_kind = PEND_EXPAND; gs.pend_tree = t; gs.pend_parent = node; gs.pend_slot = slot; gs.pend_node = idx;
+        gs.pend_depth = depth + 1;
+    }
+    wave_sync();
+    return true;
+}
+
+// K4 second half: policy/value row of the leaf -> child record, link into the parent, backup(-value, 1)
+template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+    const int node = gs.pend_parent, slot = gs.pend_slot, idx = gs.pend_node, depth = gs.pend_depth;
+    NodeRef<G> nd = node_at(E, g, t, idx);
+    copy_board<G>(S.board, nd.board());
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    make_priors<G>(E, g, gs, ts, t, S, E.nn_policy + (size_t)g * G::A, n_legal);
+    write_children_from_scratch<G>(nd, S, n_legal);
+    NodeRef<G> pn = node_at(E, g, t, node);
+    if (lane_id() == 0) {
+        nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0;
+        pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1);
+    }
+    const float value = E.nn_value[g];
+    const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    wave_sync();
+    backup<G>(E, g, t, ts, S.path, depth, -value, 1u);                 // MCTS.py:511
+}
+
+// K11: prune_tree / _set_root for tree t after `action` was played.  Returns true if the tree must be
+// rebuilt with create_expand_root (MCTS.py:661-671).
+template <class G> GAZ_DEV bool prune(const DevParams<G>& E, int g, TreeState& ts, int t, int action) {
+    if (E.create_new_root || ts.root < 0) return true;
+    NodeRef<G> r = node_at(E, g, t, ts.root);
+    const int n_children = uni((int)r.hdr()->n_children);
+    int found = -1;
+    for (int base = 0; base < n_children; base += WAVE) {
+        int i = base + lane_id();
+        uint64_t m = ballot(i < n_children && r.act()[i] == (uint8_t)action);
+        if (m) { found = base + ffsll0(m); break; }
+    }
+    if (found < 0) return true;
+    const int c = uni(r.child()[found]);
+    if (c < 0) return true;                                           // (terminal leaf: never pruned on a live game)
+    const uint32_t v = uni(r.N()[found]);
+    wave_sync();
+    if (lane_id() == 0) { ts.root = c; ts.root_visits = (uint64_t)v; }   // MCTS.py:654-655
+    wave_sync();
+    return false;
+}
+
+template <class G> GAZ_DEV uint8_t* rec_of(const DevParams<G>& E, int g) { return E.recs + (size_t)g * RecLayout<G>::SIZE; }
+
+// end of MCTS.run (MCTS.py:591-613) + the bookkeeping of Self_Play.play (Self_Play.py:114-127)
+template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+    using RL = RecLayout<G>;
+    NodeRef<G> r = node_at(E, g, t, ts.root);
+    const int n = uni((int)r.hdr()->n_children);
+    if (n != uni((int)r.hdr()->n_actions)) { set_error(E.error, ERR_ROOT_NOT_EXPANDED); }
+    uint8_t* rec = rec_of(E, g);
+    const int ply = gs.n_hist;
+    float* pol = reinterpret_cast<float*>(rec + RL::OFF_POL) + (size_t)ply * G::A;
+    uint32_t* rN = reinterpret_cast<uint32_t*>(rec + RL::OFF_N) + (size_t)ply * G::A;
+    float* rW = reinterpret_cast<float*>(rec + RL::OFF_W) + (size_t)ply * G::A;
+    float* rP = reinterpret_cast<float*>(rec + RL::OFF_P) + (size_t)ply * G::A;
+    for (int a = lane_id(); a < G::A; a += WAVE) { pol[a] = 0.0f; rN[a] = 0u; rW[a] = 0.0f; rP[a] = 0.0f; }
+    wave_sync();
+    unsigned long long sumv = 0;
+    for (int i = 0; i < n; ++i) sumv += r.N()[i];
+    for (int i = lane_id(); i < n; i += WAVE) {
+        int a = r.act()[i];
+        pol[a] = (float)((double)r.N()[i] / (double)sumv);           // prob = N / sum(N)  (MCTS.py:594, Connect4.py:421-424)
+        rN[a] = r.N()[i]; rW[a] = r.W()[i]; rP[a] = r.P()[i];
+    }
+    // K10 move sampling
+    int chosen;
+    det::Event e = make_event(E, g, gs, ts, t, det::P_MOVE);
+    const double u = det::uniform(e);
+    if (!gs.tau_on[t]) {                                               // tau == 0: one-hot at first argmax N (MCTS.py:602-604)
+        uint32_t bv = 0; int bi = 0x7fffffff;
+        for (int i = lane_id(); i < n; i += WAVE) { uint32_t v = r.N()[i]; if (bi == 0x7fffffff || v > bv) { bv = v; bi = i; } }
+        wave_argmax_u32(bv, bi);
+        chosen = uni(bi);
+    } else {                                                           // tau == 1 (MCTS.py:606-612), float64
+        const double den = (double)ts.root_visits;
+        for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)r.N()[i] / den;
+        wave_sync();
+        const double s = det::np_pairwise_sum<double>(S.gam, n);
+        double acc = 0.0, last = 0.0;
+        for (int i = 0; i < n; ++i) { acc = acc + S.gam[i] / s; last = acc; }
+        acc = 0.0; chosen = n - 1;
+        for (int i = 0; i < n; ++i) { acc = acc + S.gam[i] / s; if (acc / last > u) { chosen = i; break; } }
+        wave_sync();
+    }
+    if (lane_id() == 0) {
+        ts.event += 1;
+        gs.chosen = r.act()[chosen];
+        reinterpret_cast<float*>(rec + RL::OFF_Q)[ply] = (float)((double)r.W()[chosen] / (double)r.N()[chosen]);   // Self_Play.py:117-125
+        reinterpret_cast<uint32_t*>(rec + RL::OFF_RV)[ply] = (uint32_t)ts.root_visits;
+        reinterpret_cast<uint32_t*>(rec + RL::OFF_EV)[ply] = gs.move_evals;
+    }
+    wave_sync();
+}
+
+// One launch of the wave kernel for game g: consume the pending evaluation, then run until the next one.
+template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S) {
+    using RL = RecLayout<G>;
+    GameState<G>& gs = E.games[g];
+    TreeState* trees = E.trees + (size_t)g * 2;
+
+    if (uni(gs.pend_kind) == PEND_ROOT) {
+        const int t = uni(gs.pend_tree);
+        root_post<G>(E, g, gs, trees[t], t, S);
+        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo &= ~(1 << t); gs.n_evals += 1; }
+        wave_sync();
+    } else if (uni(gs.pend_kind) == PEND_EXPAND) {
+        const int t = uni(gs.pend_tree);
+        expand_post<G>(E, g, gs, trees[t], t, S);
+        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.sims_done += 1; gs.n_evals += 1; gs.n_sims += 1; gs.move_evals += 1; }
+        wave_sync();
+    }
+
+    for (int guard = 0; guard < 100000; ++guard) {
+        const int phase = uni(gs.phase);
+        if (phase == PH_NEW_GAME) {                                    // Game.__init__ + Self_Play.__init__ (Self_Play.py:37-57)
+            for (int c = lane_id(); c < G::BPAD; c += WAVE) gs.board[c] = 0;
+            if (lane_id() == 0) {
+                gs.n_hist = 0; gs.next_player = -1; gs.roots_todo = 3; gs.phase = PH_ROOT; gs.winner = RUNNING;
+                gs.host_move = -1; gs.move_evals = 0;
+                trees[0].root = -1; trees[0].event = 0; trees[0].n_nodes = 0; trees[0].root_visits = 0;
+                trees[1].root = -1; trees[1].event = 0; trees[1].n_nodes = 0; trees[1].root_visits = 0;
+            }
+            wave_sync();
+        } else if (phase == PH_ROOT) {
+            const int todo = uni(gs.roots_todo);
+            if (todo == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
+            const int t = (todo & 1) ? 0 : 1;
+            if (root_pre<G>(E, g, gs, trees[t], t, S)) {
+                if (lane_id() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = t; }
+                wave_sync();
+                return;
+            }
+            if (lane_id() == 0) gs.roots_todo &= ~(1 << t);
+            wave_sync();
+            if (uni(*E.error)) return;
+        } else if (phase == PH_MOVE_BEGIN) {                           // Self_Play.py:82-106 + MCTS.run head (MCTS.py:542-558)
+            copy_board<G>(S.board, gs.board);
+            wave_sync();
+            const int len_legal = build_legal<G>(S.board, S.legal);
+            if (lane_id() == 0) {
+                const int num = gs.n_hist;
+                gs.tau_on[0] = (num % 2 == 0 && num / 2 < E.explore_first) ? 1 : 0;
+                gs.tau_on[1] = ((num + 1) % 2 == 0 && (num + 1) / 2 < E.explore_second) ? 1 : 0;
+                gs.runner = (gs.next_player == -1) ? 0 : 1;
+                int lim = E.run_iterations;
+                if (len_legal == 1) lim = 1; else if (lim < len_legal) lim = len_legal * 3;
+                gs.iter_limit = lim; gs.sims_done = 0; gs.fully_visited = 0; gs.move_evals = 0;
+                gs.phase = PH_SIMS;
+            }
+            wave_sync();
+        } else if (phase == PH_SIMS) {                                 // MCTS.run loop body (MCTS.py:560-587)
+            if (uni(gs.sims_done) >= uni(gs.iter_limit)) { if (lane_id() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
+            const int t = uni(gs.runner);
+            TreeState& ts = trees[t];
+            NodeRef<G> r = node_at(E, g, t, ts.root);
+            if (!uni(gs.fully_visited)) {                              // 0 not in root.child_visits (MCTS.py:564-565)
+                const int na = uni((int)r.hdr()->n_actions);
+                uint64_t zero = 0;
+                for (int base = 0; base < na; base += WAVE) { int i = base + lane_id(); zero |= ballot(i < na && r.N()[i] == 0u); }
+                if (!zero) { if (lane_id() == 0) gs.fully_visited = 1; wave_sync(); }
+            }
+            int node, depth; bool leaf_win = false; int kind;
+            if (!uni(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
+            else kind = puct_select<G>(E, g, gs, ts, t, S, node, depth, leaf_win);
+            if (kind < 0) return;
+            if (kind == 1) {                                           // terminal leaf: value 1 / 0, visits 1 (MCTS.py:573-575)
+                backup<G>(E, g, t, ts, S.path, depth, leaf_win ? 1.0f : 0.0f, 1u);
+                if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
+                wave_sync();
+            } else {
+                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth)) return;
+                if (uni(*E.error)) return;
+                if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
+                wave_sync();
+            }
+        } else if (phase == PH_MOVE_END) {
+            const int t = uni(gs.runner);
+            move_end<G>(E, g, gs, trees[t], t, S);
+            if (lane_id() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
+            wave_sync();
+            if (E.sync_moves) return;
+        } else if (phase == PH_APPLY) {                                // Self_Play.py:142-157
+            const int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            const int mover = uni(gs.next_player);
+            copy_board<G>(S.board, gs.board);
+            wave_sync();
+            const int cell = landing_cell<G>(S.board, action);
+            const bool win = wins_after<G>(S.board, cell, mover);
+            const int empties = G::DRAWS ? count_empty<G>(S.board) : 2;
+            uint8_t* rec = rec_of(E, g);
+            const int ply = gs.n_hist;
+            int winner = win ? mover : ((G::DRAWS && empties == 1) ? 0 : RUNNING);
+            wave_sync();
+            if (lane_id() == 0) {
+                gs.board[cell] = (int8_t)mover;
+                gs.hist[ply] = (uint8_t)action;
+                rec[RL::OFF_ACT + ply] = (uint8_t)action;
+                gs.n_hist = ply + 1; gs.next_player = -mover; gs.host_move = -1;
+            }
+            wave_sync();
+            bool ended = winner != RUNNING;
+            if (!ended) {
+                int todo = 0;
+                if (prune<G>(E, g, trees[0], 0, action)) todo |= 1;   // both trees prune (Self_Play.py:149-150)
+                if (prune<G>(E, g, trees[1], 1, action)) todo |= 2;
+                if (ply + 1 == E.max_actions) { winner = 0; ended = true; }   // Self_Play.py:156-157
+                else if (lane_id() == 0) { gs.roots_todo = todo; gs.phase = PH_ROOT; }
+            }
+            if (ended) {
+                if (lane_id() == 0) {
+                    gs.winner = winner;
+                    int32_t* hdr = reinterpret_cast<int32_t*>(rec);
+                    hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)(E.slot_offset + (uint32_t)g); hdr[3] = (int32_t)gs.game_seq;
+                    atomic_max(&E.stats[0], (unsigned long long)(ply + 1));            // game_stats (Self_Play.py:181-188)
+                    atomic_add(&E.stats[1], (unsigned long long)(ply + 1));
+                    atomic_add(&E.stats[2], 1ull);
+                    atomic_add(&E.stats[winner + 4], 1ull);
+                    gs.phase = PH_RING_WAIT;
+                }
+            }
+            wave_sync();
+        } else if (phase == PH_RING_WAIT) {                            // hand the finished game to the host ring
+            int slot = -1;
+            if (E.ring_cap <= 0) {                                     // no record ring configured: drop the record
+                if (lane_id() == 0) {
+                    if (E.sync_moves) gs.phase = PH_HALT;
+                    else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
+                }
+                wave_sync();
+                if (E.sync_moves) return;
+                continue;
+            }
+            if (lane_id() == 0) {
+                // single consumer (host, between launches) / many producers
+                uint32_t prod = atomic_add(&E.ring_head[0], 1u);
+                if (prod - E.ring_head[1] < (uint32_t)E.ring_cap) slot = (int)(prod % (uint32_t)E.ring_cap);
+                else atomic_add(&E.ring_head[0], (uint32_t)-1);
+            }
+            slot = shfl(slot, 0);
+            if (slot < 0) return;                                      // ring full: retry next launch
+            const uint4* src = reinterpret_cast<const uint4*>(rec_of(E, g));
+            uint4* dst = reinterpret_cast<uint4*>(E.ring + (size_t)slot * RL::SIZE);
+            for (int i = lane_id(); i < RL::SIZE / 16; i += WAVE) dst[i] = src[i];
+            wave_sync();
+            if (lane_id() == 0) {
+                if (E.sync_moves) gs.phase = PH_HALT;
+                else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
+            }
+            wave_sync();
+            if (E.sync_moves) return;
+        } else {                                                       // PH_WAIT_HOST, PH_HALT
+            return;
+        }
+    }
+    set_error(E.error, ERR_LOOP_GUARD);
+}
+
+}  // namespace gaz

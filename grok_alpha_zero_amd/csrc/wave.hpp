@@ -1,0 +1,90 @@
+// wave.hpp — wavefront primitives for the tree kernels (gfx950, wave64).
+//
+// One wavefront (64 lanes) owns one game: control flow is wave-uniform, lanes fan out over the children
+// of a node (PUCT scoring, wave argmax), over candidate actions (terminal probe), over gamma variates
+// (Dirichlet noise) and over path levels (backup).  All cross-lane traffic is __shfl / __ballot (DPP /
+// ds_bpermute, no LDS round trip) plus a small per-wave LDS scratch.
+//
+// GAZ_HOST_EMU builds the very same device functions for the CPU with a wave of ONE lane (every
+// `for (i = lane; i < n; i += WAVE)` loop degenerates to a serial loop).  That build exists only for the
+// CPU test-suite (tests/emu), so the device logic is exercised by `pytest -m "not gpu"`; the product
+// library is always the hipcc build and never falls back to it.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#ifdef GAZ_HOST_EMU
+#include <math.h>
+#define GAZ_DEV inline
+#define GAZ_HD inline
+#define GAZ_KERNEL inline void
+#define GAZ_SHARED static thread_local
+struct char4 { signed char x, y, z, w; };
+struct uint4 { unsigned int x, y, z, w; };
+namespace gaz {
+constexpr int WAVE = 1;
+inline thread_local int emu_block_id = 0;
+inline int lane_id() { return 0; }
+inline int block_id() { return emu_block_id; }
+inline uint64_t ballot(bool p) { return p ? 1ull : 0ull; }
+template <class T> inline T shfl(T v, int) { return v; }
+template <class T> inline T shfl_xor(T v, int) { return v; }
+inline void wave_sync() {}
+inline double dsqrt(double x) { return __builtin_sqrt(x); }
+inline int popcll(uint64_t x) { return __builtin_popcountll(x); }
+inline int ffsll0(uint64_t x) { return __builtin_ctzll(x); }   // index of lowest set bit
+inline int flsll0(uint64_t x) { return 63 - __builtin_clzll(x); }
+template <class T> inline T atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+}  // namespace gaz
+#else
+#include <hip/hip_runtime.h>
+#define GAZ_DEV __device__ __forceinline__
+#define GAZ_HD __host__ __device__ __forceinline__
+#define GAZ_KERNEL __global__ void
+#define GAZ_SHARED __shared__
+namespace gaz {
+constexpr int WAVE = 64;
+GAZ_DEV int lane_id() { return threadIdx.x & 63; }
+GAZ_DEV int block_id() { return blockIdx.x; }
+GAZ_DEV uint64_t ballot(bool p) { return __ballot(p); }
+template <class T> GAZ_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }
+template <class T> GAZ_DEV T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+// one wave per workgroup: s_barrier is a no-op rendezvous but orders LDS traffic for the compiler
+GAZ_DEV void wave_sync() { __syncthreads(); }
+GAZ_DEV double dsqrt(double x) { return __dsqrt_rn(x); }
+GAZ_DEV int popcll(uint64_t x) { return __popcll(x); }
+GAZ_DEV int ffsll0(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+GAZ_DEV int flsll0(uint64_t x) { return 63 - __clzll((long long)x); }
+template <class T> GAZ_DEV T atomic_add(T* p, T v) { return atomicAdd(p, v); }
+template <class T> GAZ_DEV T atomic_max(T* p, T v) { return atomicMax(p, v); }
+}  // namespace gaz
+#endif
+
+namespace gaz {
+// wave argmax over (score, index): largest score wins, ties -> LOWEST index (np.argmax semantics,
+// MCTS.py:191).  Lanes holding no candidate pass idx = INT32_MAX.
+GAZ_DEV void wave_argmax(double& score, int& idx) {
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double os = shfl_xor(score, m);
+        int oi = shfl_xor(idx, m);
+        bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || os > score || (os == score && oi < idx));
+        if (take) { score = os; idx = oi; }
+    }
+#endif
+}
+// wave max of uint32 with lowest index on ties (np.argmax over child_visits, MCTS.py:604)
+GAZ_DEV void wave_argmax_u32(uint32_t& v, int& idx) {
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint32_t ov = shfl_xor(v, m);
+        int oi = shfl_xor(idx, m);
+        bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx));
+        if (take) { v = ov; idx = oi; }
+    }
+#endif
+}
+}  // namespace gaz

@@ -1,0 +1,241 @@
+"""ctypes binding of libgaz_engine.so (C ABI: include/gaz_engine.h) — the MI355X batched self-play engine.
+
+The library is the hipcc build in this package directory; if it is missing the import of this module's
+`load_library()` raises — there is no CPU fallback on the product path.  (tests/ may hand an explicit
+`lib_path` to exercise the host logic against the one-lane CPU emulation build under tests/emu.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_PKG, "libgaz_engine.so")
+
+GAME_IDS = {"TicTacToe": 0, "Connect4": 1, "Gomoku": 2}
+GAME_DIMS = {0: (3, 3, 2, 9), 1: (6, 7, 4, 7), 2: (15, 15, 2, 225)}  # H, W, C, A
+SEARCH_PUCT, SEARCH_GUMBEL = 0, 1
+EVAL_HASH, EVAL_RESNET, EVAL_EXTERNAL = 0, 1, 2
+PH_WAIT_HOST, PH_HALT = 5, 8
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("game", C.c_int32), ("search", C.c_int32), ("n_games", C.c_int32), ("run_iterations", C.c_int32),
+                ("max_actions", C.c_int32), ("num_explore_actions_first", C.c_int32), ("num_explore_actions_second", C.c_int32),
+                ("c_puct_init", C.c_double), ("c_puct_base", C.c_double), ("dirichlet_alpha", C.c_double),
+                ("dirichlet_epsilon", C.c_double), ("use_dirichlet", C.c_int32), ("create_new_root", C.c_int32),
+                ("sync_moves", C.c_int32), ("nodes_per_tree", C.c_int32), ("ring_capacity", C.c_int32),
+                ("seed", C.c_uint64), ("slot_offset", C.c_uint32), ("evaluator", C.c_int32), ("hash_salt", C.c_uint32),
+                ("device", C.c_int32), ("net_blocks", C.c_int32), ("net_filters", C.c_int32), ("policy_is_logits", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class RecordLayout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("record_bytes", "max_T", "A", "t_pad", "off_hdr", "off_actions", "off_q",
+                                         "off_root_visits", "off_evals", "off_policy", "off_N", "off_W", "off_P")]
+
+
+_LIBS = {}
+
+
+def load_library(lib_path=None):
+    path = lib_path or DEFAULT_LIB
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()'); "
+                           "there is no CPU fallback")
+    L = C.CDLL(path)
+    H = C.c_void_p
+    L.gaz_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(H)]
+    L.gaz_engine_destroy.argtypes = [H]; L.gaz_engine_destroy.restype = None
+    L.gaz_engine_last_error.argtypes = [H]; L.gaz_engine_last_error.restype = C.c_char_p
+    L.gaz_engine_load_weights.argtypes = [H, C.POINTER(Tensor), C.c_int32]
+    L.gaz_engine_reset_games.argtypes = [H, C.POINTER(C.c_int32), C.c_int32]
+    L.gaz_engine_run_move.argtypes = [H, C.POINTER(C.c_int32)]
+    L.gaz_engine_get_root_stats.argtypes = [H] + [C.c_void_p] * 8
+    L.gaz_engine_apply_moves.argtypes = [H, C.POINTER(C.c_int32)]
+    L.gaz_engine_run_waves.argtypes = [H, C.c_int32]
+    L.gaz_engine_wave_begin.argtypes = [H]
+    L.gaz_engine_wave_end.argtypes = [H]
+    L.gaz_engine_batch_ptrs.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.gaz_engine_read_batch.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.gaz_engine_write_outputs.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.gaz_engine_record_layout.argtypes = [H, C.POINTER(RecordLayout)]
+    L.gaz_engine_drain_finished.argtypes = [H, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.gaz_engine_get_stats.argtypes = [H, C.POINTER(C.c_uint64)]
+    L.gaz_engine_synchronize.argtypes = [H]
+    L.gaz_engine_timing_reset.argtypes = [H, C.c_int32]
+    L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
+              "wave_end", "batch_ptrs", "read_batch", "write_outputs", "record_layout", "drain_finished", "get_stats",
+              "synchronize", "timing_reset", "timing_get"):
+        getattr(L, "gaz_engine_" + f).restype = C.c_int
+    _LIBS[path] = L
+    return L
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class SelfPlayEngine:
+    """G concurrent self-play games on one GPU.  Mirrors, per game, what Self_Play(...).play() does in the
+    reference (Self_Play.py:16-208) with MCTS.run / prune_tree underneath (MCTS.py:528-671)."""
+
+    def __init__(self, game, n_games, run_iterations, max_actions, num_explore_actions_first, num_explore_actions_second,
+                 c_puct_init, dirichlet_alpha, seed, *, c_puct_base=19652.0, dirichlet_epsilon=0.25, use_dirichlet=True,
+                 create_new_root=False, sync_moves=False, nodes_per_tree=0, ring_capacity=None, slot_offset=0,
+                 evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
+                 policy_is_logits=False, lib_path=None):
+        self.L = load_library(lib_path)
+        self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
+        self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
+        self.n_games = n_games
+        if ring_capacity is None:
+            ring_capacity = 2 * n_games
+        self.cfg = EngineConfig(self.game_id, search, n_games, run_iterations, max_actions, num_explore_actions_first,
+                                num_explore_actions_second, c_puct_init, c_puct_base, dirichlet_alpha, dirichlet_epsilon,
+                                int(use_dirichlet), int(create_new_root), int(sync_moves), nodes_per_tree, ring_capacity,
+                                seed, slot_offset, evaluator, hash_salt, device, net_blocks, net_filters, int(policy_is_logits))
+        self.h = C.c_void_p()
+        if self.L.gaz_engine_create(C.byref(self.cfg), C.byref(self.h)):
+            raise EngineError(self.L.gaz_engine_last_error(None).decode())
+        self.layout = RecordLayout()
+        self._ck(self.L.gaz_engine_record_layout(self.h, C.byref(self.layout)))
+
+    def _ck(self, rc):
+        if rc:
+            raise EngineError(self.L.gaz_engine_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.gaz_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def load_weights(self, named_arrays):
+        keep = []
+        arr = (Tensor * len(named_arrays))()
+        for i, (name, a) in enumerate(named_arrays.items()):
+            a = np.ascontiguousarray(a, np.float32)
+            keep.append(a)
+            arr[i] = Tensor(name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+        self._ck(self.L.gaz_engine_load_weights(self.h, arr, len(named_arrays)))
+
+    # ---- synchronous per-move API ---------------------------------------------------------------------
+    def run_move(self):
+        n = C.c_int32()
+        self._ck(self.L.gaz_engine_run_move(self.h, C.byref(n)))
+        return n.value
+
+    def root_stats(self):
+        G, A = self.n_games, self.A
+        out = dict(N=np.zeros((G, A), np.uint32), W=np.zeros((G, A), np.float32), P=np.zeros((G, A), np.float32),
+                   policy=np.zeros((G, A), np.float32), root_visits=np.zeros(G, np.uint32), q=np.zeros(G, np.float32),
+                   chosen=np.zeros(G, np.int32), phase=np.zeros(G, np.int32))
+        self._ck(self.L.gaz_engine_get_root_stats(self.h, *[out[k].ctypes.data for k in
+                                                           ("N", "W", "P", "policy", "root_visits", "q", "chosen", "phase")]))
+        return out
+
+    def apply_moves(self, moves=None):
+        if moves is None:
+            self._ck(self.L.gaz_engine_apply_moves(self.h, None))
+        else:
+            m = np.ascontiguousarray(moves, np.int32)
+            self._ck(self.L.gaz_engine_apply_moves(self.h, m.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def reset_games(self, slots=None):
+        if slots is None:
+            self._ck(self.L.gaz_engine_reset_games(self.h, None, 0))
+        else:
+            s = np.ascontiguousarray(slots, np.int32)
+            self._ck(self.L.gaz_engine_reset_games(self.h, s.ctypes.data_as(C.POINTER(C.c_int32)), s.size))
+
+    # ---- continuous self-play -------------------------------------------------------------------------
+    def run_waves(self, n):
+        self._ck(self.L.gaz_engine_run_waves(self.h, int(n)))
+
+    def synchronize(self):
+        self._ck(self.L.gaz_engine_synchronize(self.h))
+
+    # ---- external evaluator ---------------------------------------------------------------------------
+    def wave_begin(self):
+        self._ck(self.L.gaz_engine_wave_begin(self.h))
+
+    def read_batch(self):
+        x = np.zeros((self.n_games, self.H, self.W, self.Cc), np.int8)
+        pend = np.zeros(self.n_games, np.int32)
+        self._ck(self.L.gaz_engine_read_batch(self.h, x.ctypes.data, pend.ctypes.data))
+        return x, pend
+
+    def write_outputs(self, policy, value):
+        p = np.ascontiguousarray(policy, np.float32); v = np.ascontiguousarray(value, np.float32)
+        assert p.shape == (self.n_games, self.A) and v.size == self.n_games
+        self._ck(self.L.gaz_engine_write_outputs(self.h, p.ctypes.data, v.ctypes.data))
+
+    def batch_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.L.gaz_engine_batch_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- results --------------------------------------------------------------------------------------
+    def stats(self):
+        out = (C.c_uint64 * 8)()
+        self._ck(self.L.gaz_engine_get_stats(self.h, out))
+        s = [int(x) for x in out]
+        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7])
+
+    def drain_finished(self, max_records=None):
+        """Finished games as dicts: actions, policies [T,A], q, z, values (=0.5(z+q), Self_Play.py:165-172),
+        root_N/W/P [T,A], root_visits, evals, winner, slot, game_seq."""
+        lay = self.layout
+        cap = max_records or max(self.cfg.ring_capacity, 1)
+        buf = np.zeros((cap, lay.record_bytes), np.uint8)
+        n = C.c_int32()
+        self._ck(self.L.gaz_engine_drain_finished(self.h, buf.ctypes.data, cap, C.byref(n)))
+        return [self.decode_record(buf[i]) for i in range(n.value)]
+
+    def decode_record(self, raw):
+        lay, A = self.layout, self.A
+        hdr = raw[lay.off_hdr:lay.off_hdr + 16].view(np.int32)
+        T, winner, slot, seq = (int(x) for x in hdr)
+
+        def arr(off, dt, shape):
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            return raw[off:off + n].view(dt).reshape(shape).copy()
+        actions = arr(lay.off_actions, np.uint8, (lay.t_pad,))[:T].astype(np.int32)
+        q = arr(lay.off_q, np.float32, (lay.max_T,))[:T]
+        mover = np.where(np.arange(T) % 2 == 0, -1.0, 1.0).astype(np.float32)   # target_z.append(next_player), Self_Play.py:127
+        z = mover.copy()
+        if winner == -1 and T and z[-1] == -1.0:
+            z *= -1.0
+        elif winner == 0:
+            z[:] = 0.0
+        return dict(T=T, winner=winner, slot=slot, game_seq=seq, actions=actions, q=q, z=z,
+                    values=(np.float32(0.5) * (z + q)).astype(np.float32),
+                    policies=arr(lay.off_policy, np.float32, (lay.max_T, A))[:T],
+                    root_N=arr(lay.off_N, np.uint32, (lay.max_T, A))[:T], root_W=arr(lay.off_W, np.float32, (lay.max_T, A))[:T],
+                    root_P=arr(lay.off_P, np.float32, (lay.max_T, A))[:T],
+                    root_visits=arr(lay.off_root_visits, np.uint32, (lay.max_T,))[:T],
+                    evals=arr(lay.off_evals, np.uint32, (lay.max_T,))[:T])
+
+    # ---- measurement ----------------------------------------------------------------------------------
+    def timing_reset(self, enable=True):
+        self._ck(self.L.gaz_engine_timing_reset(self.h, int(enable)))
+
+    def timing(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        d, e = C.c_int64(), C.c_int64()
+        self._ck(self.L.gaz_engine_timing_get(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return dict(ms_tree=a.value, ms_eval=b.value, ms_dominant=c.value, n_dominant=d.value, n_waves=e.value)

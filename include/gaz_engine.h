@@ -1,0 +1,111 @@
+/*
+ * gaz_engine.h — C ABI of the MI355X batched self-play engine (libgaz_engine.so).
+ *
+ * The reference (subtotechnoblade/Grok_Alpha_Zero, pure Python) has no FFI; its boundaries are the
+ * duck-typed Python surfaces listed below.  The Python package grok_alpha_zero_amd/ re-presents those
+ * surfaces (same names / arguments) on top of this ABI; INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add.  Every entry point returns 0 on success, non-zero on failure
+ * (gaz_engine_last_error gives the text); no exceptions, no torch types, caller-owned buffers,
+ * one host thread per engine (= per GPU), HIP streams internal.
+ *
+ * Reference interface replaced by each entry point (file:line under /root/reference):
+ *   gaz_engine_create          Self_Play.__init__ building MCTS x2 per game   Self_Play.py:16-69, MCTS.py:78-132
+ *                              + run_self_play's worker / server start-up      Self_Play.py:259-363
+ *   gaz_engine_load_weights    rt.InferenceSession(onnx_path) in the server    Client_Server.py:119-120
+ *   gaz_engine_reset_games     self_play_task -> game_class()                  Self_Play.py:237-245
+ *   gaz_engine_run_move        MCTS.run(iteration_limit) for every live game   MCTS.py:528-618 (Self_Play.py:97-106)
+ *   gaz_engine_get_root_stats  the move_probs rows MCTS.run returns            MCTS.py:591-600
+ *   gaz_engine_apply_moves     game.do_action + mcts1/2.prune_tree             Self_Play.py:142-157, MCTS.py:657-671
+ *   gaz_engine_run_waves       the whole Self_Play.play loop, device resident  Self_Play.py:71-157
+ *   gaz_engine_wave_begin/end  session.run(["policy","value"], {"inputs": x})  MCTS.py:224-235, Client_Server.py:28-55,162-217
+ *   gaz_engine_drain_finished  the per-game arrays play() hands to HDF5        Self_Play.py:159-175
+ *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
+ */
+#ifndef GAZ_ENGINE_H
+#define GAZ_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gaz_engine gaz_engine;
+
+enum { GAZ_GAME_TICTACTOE = 0, GAZ_GAME_CONNECT4 = 1, GAZ_GAME_GOMOKU = 2 };
+enum { GAZ_SEARCH_PUCT = 0, GAZ_SEARCH_GUMBEL = 1 };
+enum { GAZ_EVAL_HASH = 0,      /* synthetic bit-reproducible evaluator (parity tests) */
+       GAZ_EVAL_RESNET = 1,    /* the ResNet policy/value network, HIP MFMA kernels */
+       GAZ_EVAL_EXTERNAL = 2   /* caller evaluates the batch between wave_begin / wave_end */ };
+
+typedef struct {
+    int32_t game;                 /* GAZ_GAME_* */
+    int32_t search;               /* GAZ_SEARCH_* */
+    int32_t n_games;              /* concurrent games on this GPU */
+    int32_t run_iterations;       /* iteration_limit passed to MCTS.run (Self_Play passes int(1.5*MCTS_iteration_limit)) */
+    int32_t max_actions;          /* train_config["max_actions"] */
+    int32_t num_explore_actions_first, num_explore_actions_second;
+    double c_puct_init, c_puct_base;
+    double dirichlet_alpha, dirichlet_epsilon;
+    int32_t use_dirichlet;
+    int32_t create_new_root;      /* train_config.get("create_new_root", False) */
+    int32_t sync_moves;           /* 1: stop after each move for get_root_stats/apply_moves; 0: continuous self-play */
+    int32_t nodes_per_tree;       /* arena capacity per (game, tree); 0 = default for the game */
+    int32_t ring_capacity;        /* finished-game records kept for drain_finished; 0 = keep none */
+    uint64_t seed;
+    uint32_t slot_offset;         /* global slot of local game 0 (rank * n_games) */
+    int32_t evaluator;            /* GAZ_EVAL_* */
+    uint32_t hash_salt;
+    int32_t device;               /* HIP device ordinal */
+    /* ResNet (evaluator == GAZ_EVAL_RESNET): trunk of `net_blocks` pre-activation blocks x `net_filters` */
+    int32_t net_blocks, net_filters;
+    int32_t policy_is_logits;     /* 1: evaluator emits raw logits (Gumbel), 0: probabilities (softmax) */
+} gaz_engine_config;
+
+typedef struct {
+    const char* name;             /* e.g. "stem.conv.weight" — see grok_alpha_zero_amd/net.py */
+    const float* data;            /* host pointer, float32, C-contiguous */
+    int64_t numel;
+} gaz_tensor;
+
+/* layout of one finished-game record in the byte blob returned by drain_finished */
+typedef struct {
+    int32_t record_bytes, max_T, A, t_pad;
+    int32_t off_hdr, off_actions, off_q, off_root_visits, off_evals, off_policy, off_N, off_W, off_P;
+} gaz_record_layout;
+
+int gaz_engine_create(const gaz_engine_config* cfg, gaz_engine** out);
+void gaz_engine_destroy(gaz_engine* h);
+const char* gaz_engine_last_error(gaz_engine* h);   /* h may be NULL: last create() error */
+
+int gaz_engine_load_weights(gaz_engine* h, const gaz_tensor* tensors, int32_t n);
+int gaz_engine_reset_games(gaz_engine* h, const int32_t* slots, int32_t n);   /* slots NULL = all */
+
+/* synchronous per-move API (cfg.sync_moves = 1) */
+int gaz_engine_run_move(gaz_engine* h, int32_t* n_waiting);                    /* runs waves until every live game finished its MCTS.run */
+int gaz_engine_get_root_stats(gaz_engine* h, uint32_t* out_N, float* out_W, float* out_P, float* out_policy,
+                              uint32_t* out_root_visits, float* out_q, int32_t* out_chosen, int32_t* out_phase);
+                              /* [n_games][A] x4, [n_games] x4; any pointer may be NULL */
+int gaz_engine_apply_moves(gaz_engine* h, const int32_t* moves);               /* moves NULL / entry < 0 = play the sampled move */
+
+/* continuous device-resident self-play (cfg.sync_moves = 0) */
+int gaz_engine_run_waves(gaz_engine* h, int32_t n_waves);
+
+/* external evaluator: wave_begin leaves the batch in HBM, wave_end consumes policy/value written by the caller */
+int gaz_engine_wave_begin(gaz_engine* h);
+int gaz_engine_wave_end(gaz_engine* h);
+int gaz_engine_batch_ptrs(gaz_engine* h, void** d_inputs_i8, void** d_policy_f32, void** d_value_f32);   /* device pointers */
+int gaz_engine_read_batch(gaz_engine* h, int8_t* inputs, int32_t* pending);    /* host copies: [n_games][H*W*C], [n_games] */
+int gaz_engine_write_outputs(gaz_engine* h, const float* policy, const float* value);   /* host -> device rows */
+
+int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* out);
+int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out);
+int gaz_engine_get_stats(gaz_engine* h, uint64_t out[8]);   /* [0..5] game_stats, [6] evaluator calls, [7] simulations */
+int gaz_engine_synchronize(gaz_engine* h);
+
+/* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
+int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);
+int gaz_engine_timing_get(gaz_engine* h, double* ms_tree, double* ms_eval, double* ms_dominant, int64_t* n_dominant, int64_t* n_waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""GPU suite (-m gpu): the HIP engine (libgaz_engine.so, gfx950) through the C ABI against
+ (1) the golden vectors recorded from the reference and (2) the CPU oracle on the same seeded inputs.
+Bar: actions, visit counts N, root.visits bit-exact; W, P, policies, values bit-exact as well (same f32/f64
+operation order on both sides)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")))
+
+
+def _engine(*a, **k):
+    import torch
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+    from grok_alpha_zero_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(*a, **k)
+
+
+def _play_until(eng, want, max_calls=4000, waves=64):
+    recs = []
+    for _ in range(max_calls):
+        eng.run_waves(waves)
+        recs += eng.drain_finished()
+        if want(recs):
+            return recs
+    raise AssertionError("games did not finish")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_engine_matches_reference_fixture(name):
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    seq = int(fx["game_seq"])
+    eng = _engine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), int(fx["explore_first"]),
+                  int(fx["explore_second"]), float(fx["c_puct_init"]), float(fx["dirichlet_alpha"]), int(fx["seed"]),
+                  slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8)
+    recs = _play_until(eng, lambda rs: any(r["game_seq"] == seq for r in rs))
+    r = [x for x in recs if x["game_seq"] == seq][0]
+    assert r["T"] == len(fx["actions"])
+    for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies"):
+        np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
+    np.testing.assert_array_equal(r["values"], fx["values"].reshape(-1))
+    eng.close()
+
+
+@pytest.mark.parametrize("game,G,iters,max_actions,ef,es,c,alpha", [
+    ("Connect4", 256, 60, 42, 8, 7, 2.5, 0.5),
+    ("TicTacToe", 128, 51, 9, 2, 1, 1.25, 1.0),
+    ("Gomoku", 16, 40, 10, 6, 4, 4.5, 0.05),
+])
+def test_hip_engine_matches_oracle_many_games(oracle, game, G, iters, max_actions, ef, es, c, alpha):
+    """Continuous device-resident self-play: every finished game (first two per slot) equals the oracle's."""
+    eng = _engine(game, G, iters, max_actions, ef, es, c, alpha, seed=2024, hash_salt=17, slot_offset=1000,
+                  ring_capacity=4 * G)
+    recs = _play_until(eng, lambda rs: len({(r["slot"], r["game_seq"]) for r in rs if r["game_seq"] < 2}) == 2 * G)
+    checked = 0
+    for r in recs:
+        if r["game_seq"] >= 2:
+            continue
+        o = oracle.selfplay_game(game, iters, max_actions, ef, es, c, alpha, 2024, r["slot"], r["game_seq"], hash_salt=17)
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']} seq {r['game_seq']}")
+        checked += 1
+    assert checked == 2 * G
+    st = eng.stats()
+    assert st["game_stats"][2] >= 2 * G and st["game_stats"][3] + st["game_stats"][4] + st["game_stats"][5] == st["game_stats"][2]
+    eng.close()
+
+
+def test_hip_sync_api_and_host_moves(oracle):
+    """run_move / get_root_stats / apply_moves; host-chosen moves (opening_actions style override)."""
+    from grok_alpha_zero_amd.engine import PH_HALT
+    G, iters = 32, 40
+    eng = _engine("Connect4", G, iters, 42, 8, 7, 2.5, 0.5, seed=9, hash_salt=1, sync_moves=True)
+    ora = [oracle.selfplay_game("Connect4", iters, 42, 8, 7, 2.5, 0.5, 9, g, 0, hash_salt=1) for g in range(G)]
+    for ply in range(42):
+        eng.run_move()
+        st = eng.root_stats()
+        live = [g for g in range(G) if st["phase"][g] != PH_HALT]
+        if not live:
+            break
+        for g in live:
+            np.testing.assert_array_equal(st["N"][g], ora[g]["root_N"][ply])
+            assert st["chosen"][g] == ora[g]["actions"][ply]
+        eng.apply_moves(st["chosen"])      # explicit host moves == sampled moves
+    recs = {r["slot"]: r for r in eng.drain_finished()}
+    assert len(recs) == G and all(recs[g]["T"] == ora[g]["T"] for g in range(G))
+    eng.close()
+
+
+def test_full_size_invariants():
+    """BASELINE config[1] size (4096 concurrent Connect4 games, 200 sims/move) with the synthetic evaluator:
+    size-independent properties — per ply sum(N) over root children == root.visits bookkeeping, policies sum to 1,
+    game_stats consistent, every finished game legal."""
+    G = 4096
+    eng = _engine("Connect4", G, 200, 42, 8, 7, 2.5, 0.5, seed=1, hash_salt=3, ring_capacity=2 * G)
+    recs = _play_until(eng, lambda rs: len(rs) >= 512, max_calls=400, waves=128)
+    for r in recs[:512]:
+        T = r["T"]
+        assert 7 <= T <= 42
+        assert np.allclose(r["policies"].sum(1), 1.0, atol=1e-6)
+        n_sum = r["root_N"].sum(1)
+        assert (n_sum >= 1).all()
+        # a fresh-or-reused root has visits = sum over children (+ carried visits of the reused node itself)
+        assert (r["root_visits"] >= 1).all()
+        cols = np.bincount(r["actions"], minlength=7)
+        assert cols.max() <= 6
+    st = eng.stats()["game_stats"]
+    assert st[2] >= 512 and st[3] + st[4] + st[5] == st[2] and st[0] <= 42
+    eng.close()
