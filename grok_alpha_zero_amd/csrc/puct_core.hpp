@@ -641,13 +641,14 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
             }
             wave_sync();
             bool ended = winner != RUNNING;
+            int todo = 0;
             if (!ended) {
-                int todo = 0;
                 if (prune<G>(E, g, trees[0], 0, action)) todo |= 1;   // both trees prune (Self_Play.py:149-150)
                 if (prune<G>(E, g, trees[1], 1, action)) todo |= 2;
-                if (ply + 1 == E.max_actions) { winner = 0; ended = true; }   // Self_Play.py:156-157
-                else if (lane_id() == 0) { gs.roots_todo = todo; gs.phase = PH_ROOT; }
             }
+            // Self_Play.py:155-157: reaching max_actions forces winner = 0 — even when that last action won
+            if (ply + 1 == E.max_actions) { winner = 0; ended = true; }
+            if (!ended && lane_id() == 0) { gs.roots_todo = todo; gs.phase = PH_ROOT; }
             if (ended) {
                 if (lane_id() == 0) {
                     gs.winner = winner;
