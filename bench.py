@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py — self-play positions/sec (whole job) of the MI355X engine on BASELINE.json's metric/config.
+
+A "step" = `--waves-per-step` simulation waves of the hot path over the resident batch of games (every wave =
+one tree-kernel launch + one evaluator forward over all G leaves); games restart on device as they finish, so G
+stays constant.  value = plies played by all ranks (delta game_stats[1]) / wall time of the K timed steps
+(barrier + synchronize on both sides, max over ranks).  Inputs are device resident: nothing crosses PCIe in the
+timed region except the per-step stats read-back after it ends.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=200, help="iteration_limit of every MCTS.run")
+    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--waves-per-step", type=int, default=400)
+    ap.add_argument("--evaluator", default="resnet", choices=["resnet", "hash"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, net):
+    """The oracle (C restatement of the reference's Self_Play.play, one game at a time, one evaluator call per leaf —
+    the reference's execution model) on the host cores of this box, evaluator = the same network in PyTorch fp32 on
+    CPU.  Bounded sample of the same workload (Connect4, same sims/move, same net)."""
+    import torch
+    from oracle import gaz_oracle as O
+    O.build()
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 1))
+    cores = torch.get_num_threads()
+
+    def ev(state):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(state[None].copy()))
+        return p[0].numpy(), float(v[0, 0])
+    t0 = time.time(); positions = 0; games = 0; evals = 0
+    while time.time() - t0 < args.cpu_baseline_seconds:
+        # one bounded game: cap plies so a single call stays within the sample budget
+        r = O.selfplay_game("Connect4", args.sims, 6, 8, 7, 2.5, 0.5, 1234, games, 0, evaluator=ev)
+        positions += r["T"]; games += 1; evals += r["total_evals"]
+    dt = time.time() - t0
+    return dict(value=positions / dt, unit="positions/s", cores=cores, kind="port",
+                sample=f"{games} games cut at 6 plies = {positions} positions, {evals} evaluator calls in {dt:.1f}s; "
+                       f"oracle/ C restatement, sequential games, batch-1 PyTorch fp32 CPU evaluator ({cores} threads)")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local) if torch.cuda.is_available() else None)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local)
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET, EVAL_HASH
+    from grok_alpha_zero_amd.net import Connect4Net, flops_per_position
+    from grok_alpha_zero_amd.parallel import reduce_stats
+
+    G = args.games
+    net = Connect4Net(args.blocks, seed=0).eval()
+    eng = SelfPlayEngine("Connect4", G, args.sims, 42, 8, 7, 2.5, 0.5, seed=1234, slot_offset=rank * G, device=local,
+                         evaluator=EVAL_RESNET if args.evaluator == "resnet" else EVAL_HASH, net_blocks=args.blocks,
+                         hash_salt=7, ring_capacity=0)
+    if args.evaluator == "resnet":
+        eng.load_weights(net.export_engine_weights())
+
+    def barrier():
+        eng.synchronize(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.run_waves(args.waves_per_step)
+    barrier()
+    s0 = eng.stats()
+    eng.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run_waves(args.waves_per_step)
+    barrier()
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    tm = eng.timing()
+    eng.timing_reset(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    delta = np.array([int(s1["game_stats"][1] - s0["game_stats"][1]), int(s1["game_stats"][2] - s0["game_stats"][2]),
+                      s1["evals"] - s0["evals"], s1["sims"] - s0["sims"]], np.int64)
+    total = reduce_stats(delta, world)                      # the one collective of the path: counters only
+    positions, games, evals, sims = (int(x) for x in total)
+
+    if rank == 0:
+        fl = flops_per_position(args.blocks)
+        M = G * 42
+        conv_flops = 2.0 * M * 128 * 9 * 128                 # one trunk conv launch
+        roof = None
+        if args.evaluator == "resnet" and tm["n_dominant"] > 0:
+            avg_ms = tm["ms_dominant"] / tm["n_dominant"]
+            ach = conv_flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+                        kernel="k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM M=%d N=128 K=1152)" % M,
+                        avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+        out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
+                   value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16", data="synthetic",
+                   config=dict(workload=f"Connect4 6x7, {G} concurrent games/GPU, {args.sims} sims/move (MCTS.run iteration_limit), "
+                                        f"{args.blocks}-block x128 ResNet bf16, PUCT two-tree self-play, random-init weights",
+                               games_per_gpu=G, sims_per_move=args.sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
+                               parallelism=f"games sharded x{world}, counters all-reduced"),
+                   detail=dict(positions=positions, games_finished=games, evaluator_calls=evals, simulations=sims,
+                               evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=sims / dt,
+                               eval_tflops=evals * fl["total"] / dt / 1e12,
+                               ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
+                               ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1)),
+                   roofline=roof)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, net)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,7 @@ struct gaz_engine {
     virtual int batch_ptrs(void**, void**, void**) = 0;
     virtual int read_batch(int8_t*, int32_t*) = 0;
     virtual int write_outputs(const float*, const float*) = 0;
+    virtual int evaluate(const int8_t*, int, float*, float*, int, double*) = 0;
     virtual int record_layout(gaz_record_layout*) = 0;
     virtual int drain(void* out, int max_records, int32_t* n_out) = 0;
     virtual int get_stats(uint64_t out[8]) = 0;
@@ -242,6 +243,7 @@ template <class G> struct EngineT : gaz_engine {
     int run_move(int32_t* n_waiting) override {
         if (!E.sync_moves) return fail("run_move needs sync_moves = 1");
         if (!eval) return fail("run_move needs a built-in evaluator (use wave_begin/wave_end with GAZ_EVAL_EXTERNAL)");
+        if (!eval->ready()) return fail("run_move: evaluator weights not loaded (gaz_engine_load_weights)");
         // a move needs at most iter_limit + 2 evaluations (both roots); poll the device every 16 waves
         const int max_waves = (E.run_iterations < 3 * G::A ? 3 * G::A : E.run_iterations) + 8;
         int32_t c[8];
@@ -287,6 +289,7 @@ template <class G> struct EngineT : gaz_engine {
 
     int run_waves(int n) override {
         if (!eval) return fail("run_waves needs a built-in evaluator");
+        if (!eval->ready()) return fail("run_waves: evaluator weights not loaded (gaz_engine_load_weights)");
         for (int i = 0; i < n; ++i) one_wave(true);
         HIP_OK(hipGetLastError());
         return 0;
@@ -311,6 +314,25 @@ template <class G> struct EngineT : gaz_engine {
         HIP_OK(hipMemcpyAsync(E.nn_policy, policy, (size_t)E.n_games * G::A * 4, hipMemcpyHostToDevice, stream));
         HIP_OK(hipMemcpyAsync(E.nn_value, value, (size_t)E.n_games * 4, hipMemcpyHostToDevice, stream));
         HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    int evaluate(const int8_t* in, int n, float* pol, float* val, int repeats, double* ms) override {
+        if (!eval) return fail("evaluate: no built-in evaluator");
+        if (!eval->ready()) return fail("evaluate: evaluator weights not loaded");
+        if (n <= 0 || n > E.n_games) return fail("evaluate: n must be in [1, n_games]");
+        HIP_OK(hipMemcpyAsync(E.nn_in, in, (size_t)n * G::HW * G::C, hipMemcpyHostToDevice, stream));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, n, false);      // warm-up / the measured result
+        hipEventRecord(e0, stream);
+        for (int r = 0; r < repeats; ++r) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, n, false);
+        hipEventRecord(e1, stream);
+        HIP_OK(hipMemcpyAsync(pol, E.nn_policy, (size_t)n * G::A * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(val, E.nn_value, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        float t = 0; hipEventElapsedTime(&t, e0, e1); hipEventDestroy(e0); hipEventDestroy(e1);
+        if (ms) *ms = repeats > 0 ? (double)t / repeats : 0.0;
+        HIP_OK(hipGetLastError());
         return 0;
     }
 
@@ -405,6 +427,7 @@ int gaz_engine_wave_end(gaz_engine* h) { return h->wave_end(); }
 int gaz_engine_batch_ptrs(gaz_engine* h, void** a, void** b, void** c) { return h->batch_ptrs(a, b, c); }
 int gaz_engine_read_batch(gaz_engine* h, int8_t* in, int32_t* pending) { return h->read_batch(in, pending); }
 int gaz_engine_write_outputs(gaz_engine* h, const float* p, const float* v) { return h->write_outputs(p, v); }
+int gaz_engine_evaluate(gaz_engine* h, const int8_t* in, int32_t n, float* p, float* v, int32_t repeats, double* ms) { return h->evaluate(in, n, p, v, repeats, ms); }
 int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* o) { return h->record_layout(o); }
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out) { return h->drain(out, max_records, n_out); }
 int gaz_engine_get_stats(gaz_engine* h, uint64_t out[8]) { return h->get_stats(out); }

@@ -16,6 +16,7 @@ struct Evaluator {
     virtual ~Evaluator() {}
     virtual int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) { (void)t; (void)n; (void)s; (void)err; return 0; }
     virtual void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) = 0;
+    virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
 };

@@ -64,6 +64,7 @@ def load_library(lib_path=None):
     L.gaz_engine_batch_ptrs.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.gaz_engine_read_batch.argtypes = [H, C.c_void_p, C.c_void_p]
     L.gaz_engine_write_outputs.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.gaz_engine_evaluate.argtypes = [H, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_record_layout.argtypes = [H, C.POINTER(RecordLayout)]
     L.gaz_engine_drain_finished.argtypes = [H, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.gaz_engine_get_stats.argtypes = [H, C.POINTER(C.c_uint64)]
@@ -72,7 +73,7 @@ def load_library(lib_path=None):
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
-              "wave_end", "batch_ptrs", "read_batch", "write_outputs", "record_layout", "drain_finished", "get_stats",
+              "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
               "synchronize", "timing_reset", "timing_get"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
@@ -132,6 +133,14 @@ class SelfPlayEngine:
             keep.append(a)
             arr[i] = Tensor(name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
         self._ck(self.L.gaz_engine_load_weights(self.h, arr, len(named_arrays)))
+
+    def evaluate(self, states_i8, repeats=0):
+        """Evaluator probe (Compute_Speed.py:40-63): states int8 [n,H,W,C] -> (policy [n,A], value [n], ms per batch)."""
+        x = np.ascontiguousarray(states_i8, np.int8)
+        n = x.shape[0]
+        pol = np.zeros((n, self.A), np.float32); val = np.zeros(n, np.float32); ms = C.c_double()
+        self._ck(self.L.gaz_engine_evaluate(self.h, x.ctypes.data, n, pol.ctypes.data, val.ctypes.data, repeats, C.byref(ms)))
+        return pol, val, ms.value
 
     # ---- synchronous per-move API ---------------------------------------------------------------------
     def run_move(self):

@@ -20,6 +20,7 @@
  *   gaz_engine_wave_begin/end  session.run(["policy","value"], {"inputs": x})  MCTS.py:224-235, Client_Server.py:28-55,162-217
  *   gaz_engine_drain_finished  the per-game arrays play() hands to HDF5        Self_Play.py:159-175
  *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
+ *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  */
 #ifndef GAZ_ENGINE_H
 #define GAZ_ENGINE_H
@@ -95,6 +96,9 @@ int gaz_engine_wave_end(gaz_engine* h);
 int gaz_engine_batch_ptrs(gaz_engine* h, void** d_inputs_i8, void** d_policy_f32, void** d_value_f32);   /* device pointers */
 int gaz_engine_read_batch(gaz_engine* h, int8_t* inputs, int32_t* pending);    /* host copies: [n_games][H*W*C], [n_games] */
 int gaz_engine_write_outputs(gaz_engine* h, const float* policy, const float* value);   /* host -> device rows */
+
+/* run the built-in evaluator on a host batch: inputs int8 [n][H*W*C] -> policy f32 [n][A], value f32 [n]; n <= n_games */
+int gaz_engine_evaluate(gaz_engine* h, const int8_t* inputs, int32_t n, float* policy, float* value, int32_t repeats, double* ms_per_batch);
 
 int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* out);
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out);
