@@ -44,8 +44,8 @@ def cpu_baseline(args, net):
     import torch
     from oracle import gaz_oracle as O
     O.build()
-    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 1))
-    cores = torch.get_num_threads()
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
 
     def ev(state):
         with torch.no_grad():
@@ -54,11 +54,11 @@ def cpu_baseline(args, net):
     t0 = time.time(); positions = 0; games = 0; evals = 0
     while time.time() - t0 < args.cpu_baseline_seconds:
         # one bounded game: cap plies so a single call stays within the sample budget
-        r = O.selfplay_game("Connect4", args.sims, 6, 8, 7, 2.5, 0.5, 1234, games, 0, evaluator=ev)
+        r = O.selfplay_game("Connect4", args.sims, 3, 8, 7, 2.5, 0.5, 1234, games, 0, evaluator=ev)
         positions += r["T"]; games += 1; evals += r["total_evals"]
     dt = time.time() - t0
     return dict(value=positions / dt, unit="positions/s", cores=cores, kind="port",
-                sample=f"{games} games cut at 6 plies = {positions} positions, {evals} evaluator calls in {dt:.1f}s; "
+                sample=f"{games} games cut at 3 plies = {positions} positions, {evals} evaluator calls in {dt:.1f}s; "
                        f"oracle/ C restatement, sequential games, batch-1 PyTorch fp32 CPU evaluator ({cores} threads)")
 
 
@@ -91,8 +91,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"engine ready: {G} games, {args.sims} sims/move, evaluator={args.evaluator}")
+    for i in range(args.warmup):
         eng.run_waves(args.waves_per_step)
+        eng.synchronize()
+        log(f"warmup step {i} done")
     barrier()
     s0 = eng.stats()
     eng.timing_reset(True)
@@ -101,6 +108,7 @@ def main():
         eng.run_waves(args.waves_per_step)
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     s1 = eng.stats()
     tm = eng.timing()
     eng.timing_reset(False)
