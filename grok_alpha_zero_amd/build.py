@@ -7,7 +7,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB = os.path.join(_PKG, "libgaz_engine.so")
 SOURCES = ["engine.hip", "resnet.hip"]
 # -ffp-contract=off: the injected-noise samplers and PUCT scores must not be FMA-contracted (bit parity)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _stale():

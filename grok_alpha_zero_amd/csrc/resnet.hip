@@ -125,28 +125,100 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
             for (int j = 0; j < NB; ++j) breg[j] = w4[(size_t)(tap + 1) * (BN * SLOTS) + tid + j * 256];
         }
         const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
+        // fragment addresses of this tap (the XOR swizzle only touches the slot index, so ks adds in XOR space)
+        int abase[TM], axor[TM], bbase[TN], bxor[TN]; bool aval[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int ar = lrow[tm] + halo + off;
+            abase[tm] = ar * SLOTS; axor[tm] = ar & 15; aval[tm] = (vmask[tm] >> tap) & 1u;
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = (wn * TN + tn) * 32 + l31;
+            bbase[tn] = n * SLOTS; bxor[tn] = n & 15;
+        }
+        // software pipeline over the k-steps: fragments of step ks+1 are in flight while step ks multiplies
+        uint4 afr[2][TM], bfr[2][TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfr[0][tn] = Bs[bbase[tn] + (lhi ^ bxor[tn])];
 #pragma unroll
         for (int ks = 0; ks < CIN / 16; ++ks) {
-            bf16x8 af[TM], bfr[TN];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < CIN / 16) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bfr[nxt][tn] = Bs[bbase[tn] + (((ks + 1) * 2 + lhi) ^ bxor[tn])];
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const int ar = lrow[tm] + halo + off;
-                uint4 v = As[ar * SLOTS + ((ks * 2 + lhi) ^ (ar & 15))];
-                if (!((vmask[tm] >> tap) & 1u)) v = make_uint4(0, 0, 0, 0);
-                af[tm] = *reinterpret_cast<bf16x8*>(&v);
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int n = (wn * TN + tn) * 32 + l31;
-                uint4 v = Bs[n * SLOTS + ((ks * 2 + lhi) ^ (n & 15))];
-                bfr[tn] = *reinterpret_cast<bf16x8*>(&v);
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                uint4 v = afr[cur][tm];
+                if (!aval[tm]) v = make_uint4(0, 0, 0, 0);
+                const bf16x8 af = *reinterpret_cast<bf16x8*>(&v);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
+            }
         }
+    }
+
+    if (EPI == 0) {
+        // ---- epilogue through LDS: accumulators -> fp32 tile [128][BN + 4], then whole 16-byte channel groups per
+        // thread: residual load, activation, both outputs as dwordx4 stores (full 256-B rows per 16 lanes).
+        constexpr int CT = BN + 4;
+        float* Ct = reinterpret_cast<float*>(lds);
+        __syncthreads();                            // all waves are done reading As / Bs
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = (wn * TN + tn) * 32 + l31;
+                const float sA = a.scaleA ? a.scaleA[col] : 1.0f, tA = a.shiftA ? a.shiftA[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    Ct[row * CT + col] = acc[tm][tn][r] * sA + tA;
+                }
+            }
+        __syncthreads();
+        constexpr int CHUNKS = BN / 8;              // 16-byte (8 x bf16) groups per row
+        const int chunk = tid % CHUNKS, r0 = tid / CHUNKS;
+        float sB[8], tB[8];
+        if (a.out2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sB[j] = a.scaleB[chunk * 8 + j]; tB[j] = a.shiftB[chunk * 8 + j]; }
+        }
+        for (int row = r0; row < CONV_BM; row += 256 / CHUNKS) {
+            const long gr = m0 + row;
+            if (gr >= a.M) break;
+            const float4 c0 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8]);
+            const float4 c1 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8 + 4]);
+            float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const size_t o = (size_t)gr * BN + chunk * 8;
+            if (a.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
+                const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += bf2f(rb[j]);
+            }
+            if (a.act1 == ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+            }
+            bf16_t o1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o1[j] = f2bf(v[j]);
+            *reinterpret_cast<uint4*>(a.out1 + o) = *reinterpret_cast<const uint4*>(o1);
+            if (a.out2) {
+                bf16_t o2[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o2[j] = f2bf(fmaxf(v[j] * sB[j] + tB[j], 0.0f));
+                *reinterpret_cast<uint4*>(a.out2 + o) = *reinterpret_cast<const uint4*>(o2);
+            }
+        }
+        return;
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
