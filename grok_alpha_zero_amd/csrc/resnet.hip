@@ -19,240 +19,13 @@
 #include <string>
 #include <vector>
 #include "evaluator.hpp"
+#include "conv3x3.hpp"
 
 namespace gaz {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned short bf16_t;
-
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
 static bf16_t f2bf_host(float f) {
     unsigned u; memcpy(&u, &f, 4);
     return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
-
-struct ConvArgs {
-    const bf16_t* in;        // [M][CIN] NHWC rows
-    const bf16_t* wgt;       // [9][BN][CIN]
-    const float* scaleA;     // [BN] or null (=1)
-    const float* shiftA;     // [BN]
-    const bf16_t* res;       // [M][BN] residual or null
-    bf16_t* out1;            // [M][BN]: act1(acc*scaleA + shiftA + res)
-    int act1;
-    const float* scaleB;     // second output: relu(out1*scaleB + shiftB), null = none
-    const float* shiftB;
-    bf16_t* out2;
-    // heads epilogue (EPI == 1): features relu((acc + shiftA[c]) * fs[cell*8+c] + ft[cell*8+c]) -> f32 [B][HW*8]
-    const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft;
-    float* p_feat; float* v_feat;
-    int M, H, W;
-};
-
-constexpr int CONV_BM = 128;
-constexpr int CONV_HALO_MAX = 16;
-
-template <int CIN, int BN, int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
-    static_assert(WM * WN == 4 && WM * TM * 32 == CONV_BM && WN * TN * 32 == BN, "tile shape");
-    constexpr int SLOTS = CIN / 8;                 // 16-byte slots per row
-    constexpr int AROWS = CONV_BM + 2 * CONV_HALO_MAX;
-    constexpr int NB = BN * SLOTS / 256;           // weight uint4 per thread per tap
-    extern __shared__ uint4 lds[];
-    uint4* As = lds;
-    uint4* Bs = lds + AROWS * SLOTS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const long m0 = (long)blockIdx.x * CONV_BM;
-    const int halo = a.W + 1, HW = a.H * a.W;
-
-    // ---- stage the activation image: rows [m0 - halo, m0 + BM + halo)
-    const uint4* in4 = reinterpret_cast<const uint4*>(a.in);
-    for (int idx = tid; idx < (CONV_BM + 2 * halo) * SLOTS; idx += 256) {
-        const int lr = idx / SLOTS, s = idx % SLOTS;
-        const long gr = m0 - halo + lr;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gr >= 0 && gr < a.M) v = in4[gr * SLOTS + s];
-        As[lr * SLOTS + (s ^ (lr & 15))] = v;
-    }
-    // ---- per-lane geometry of the TM row tiles this wave owns
-    int lrow[TM]; unsigned vmask[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        lrow[tm] = (wm * TM + tm) * 32 + l31;
-        const long gr = m0 + lrow[tm];
-        const int cell = (int)(gr % HW), y = cell / a.W, x = cell % a.W;
-        unsigned m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool ok = gr < a.M && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
-            m |= (ok ? 1u : 0u) << t;
-        }
-        vmask[tm] = m;
-    }
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-
-    const uint4* w4 = reinterpret_cast<const uint4*>(a.wgt);
-    uint4 breg[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) breg[j] = w4[(size_t)(tid + j * 256)];
-
-    for (int tap = 0; tap < 9; ++tap) {
-        __syncthreads();                            // everyone is done with the previous weight slice (and As is staged)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int idx = tid + j * 256, n = idx / SLOTS, s = idx % SLOTS;
-            Bs[n * SLOTS + (s ^ (n & 15))] = breg[j];
-        }
-        __syncthreads();
-        if (tap + 1 < 9) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) breg[j] = w4[(size_t)(tap + 1) * (BN * SLOTS) + tid + j * 256];
-        }
-        const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
-        // fragment addresses of this tap (the XOR swizzle only touches the slot index, so ks adds in XOR space)
-        int abase[TM], axor[TM], bbase[TN], bxor[TN]; bool aval[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int ar = lrow[tm] + halo + off;
-            abase[tm] = ar * SLOTS; axor[tm] = ar & 15; aval[tm] = (vmask[tm] >> tap) & 1u;
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = (wn * TN + tn) * 32 + l31;
-            bbase[tn] = n * SLOTS; bxor[tn] = n & 15;
-        }
-        // software pipeline over the k-steps: fragments of step ks+1 are in flight while step ks multiplies
-        uint4 afr[2][TM], bfr[2][TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bfr[0][tn] = Bs[bbase[tn] + (lhi ^ bxor[tn])];
-#pragma unroll
-        for (int ks = 0; ks < CIN / 16; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < CIN / 16) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bfr[nxt][tn] = Bs[bbase[tn] + (((ks + 1) * 2 + lhi) ^ bxor[tn])];
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                uint4 v = afr[cur][tm];
-                if (!aval[tm]) v = make_uint4(0, 0, 0, 0);
-                const bf16x8 af = *reinterpret_cast<bf16x8*>(&v);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
-            }
-        }
-    }
-
-    if (EPI == 0) {
-        // ---- epilogue through LDS: accumulators -> fp32 tile [128][BN + 4], then whole 16-byte channel groups per
-        // thread: residual load, activation, both outputs as dwordx4 stores (full 256-B rows per 16 lanes).
-        constexpr int CT = BN + 4;
-        float* Ct = reinterpret_cast<float*>(lds);
-        __syncthreads();                            // all waves are done reading As / Bs
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = (wn * TN + tn) * 32 + l31;
-                const float sA = a.scaleA ? a.scaleA[col] : 1.0f, tA = a.shiftA ? a.shiftA[col] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    Ct[row * CT + col] = acc[tm][tn][r] * sA + tA;
-                }
-            }
-        __syncthreads();
-        constexpr int CHUNKS = BN / 8;              // 16-byte (8 x bf16) groups per row
-        const int chunk = tid % CHUNKS, r0 = tid / CHUNKS;
-        float sB[8], tB[8];
-        if (a.out2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sB[j] = a.scaleB[chunk * 8 + j]; tB[j] = a.shiftB[chunk * 8 + j]; }
-        }
-        for (int row = r0; row < CONV_BM; row += 256 / CHUNKS) {
-            const long gr = m0 + row;
-            if (gr >= a.M) break;
-            const float4 c0 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8]);
-            const float4 c1 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8 + 4]);
-            float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const size_t o = (size_t)gr * BN + chunk * 8;
-            if (a.res) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
-                const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += bf2f(rb[j]);
-            }
-            if (a.act1 == ACT_RELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
-            }
-            bf16_t o1[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = f2bf(v[j]);
-            *reinterpret_cast<uint4*>(a.out1 + o) = *reinterpret_cast<const uint4*>(o1);
-            if (a.out2) {
-                bf16_t o2[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o2[j] = f2bf(fmaxf(v[j] * sB[j] + tB[j], 0.0f));
-                *reinterpret_cast<uint4*>(a.out2 + o) = *reinterpret_cast<const uint4*>(o2);
-            }
-        }
-        return;
-    }
-
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = (wn * TN + tn) * 32 + l31;
-            const float sA = a.scaleA ? a.scaleA[col] : 1.0f, tA = a.shiftA ? a.shiftA[col] : 0.0f;
-            float sB = 0.f, tB = 0.f;
-            if (EPI == 0 && a.out2) { sB = a.scaleB[col]; tB = a.shiftB[col]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const long gr = m0 + row;
-                if (gr >= a.M) continue;
-                float v = acc[tm][tn][r] * sA + tA;
-                if (EPI == 0) {
-                    const size_t o = (size_t)gr * BN + col;
-                    if (a.res) v += bf2f(a.res[o]);
-                    if (a.act1 == ACT_RELU) v = fmaxf(v, 0.0f);
-                    a.out1[o] = f2bf(v);
-                    if (a.out2) a.out2[o] = f2bf(fmaxf(v * sB + tB, 0.0f));
-                } else {
-                    if (col < 16) {     // 0-7 policy conv channels, 8-15 value conv channels
-                        const long b = gr / HW; const int cell = (int)(gr % HW), c = col & 7;
-                        const int f = cell * 8 + c;
-                        if (col < 8) a.p_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.p_fs[f] + a.p_ft[f], 0.0f);
-                        else a.v_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.v_fs[f] + a.v_ft[f], 0.0f);
-                    }
-                }
-            }
-        }
-    }
 }
 
 // ---- stem: Conv3x3(C_in = 4, int8 planes) -> 128, BN, exact GELU; second output relu(bn1_0(x))
@@ -441,8 +214,8 @@ struct ResNetEvaluator : Evaluator {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1;
         a.scaleB = sB; a.shiftB = tB; a.out2 = out2; a.M = M; a.H = H; a.W = W;
-        const size_t lds = (size_t)((CONV_BM + 2 * CONV_HALO_MAX) * 16 + 128 * 16) * 16;
-        hipLaunchKernelGGL((k_conv3x3<128, 128, 2, 2, 2, 2, 0>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(256), lds, s, a);
+        const size_t lds = conv_lds_bytes<128, 128>();
+        hipLaunchKernelGGL((k_conv3x3<128, 128, 4, 2, 2, 2, 0>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(CONV_THREADS), lds, s, a);
         n_trunk_launches++;
     }
 
@@ -469,8 +242,8 @@ struct ResNetEvaluator : Evaluator {
             a.in = X; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
             a.p_fs = f32["p.bn0.scale"]; a.p_ft = f32["p.bn0.shift"]; a.v_fs = f32["v.bn0.scale"]; a.v_ft = f32["v.bn0.shift"];
             a.p_feat = pfeat; a.v_feat = vfeat;
-            const size_t lds = (size_t)((CONV_BM + 2 * CONV_HALO_MAX) * 16 + 32 * 16) * 16;
-            hipLaunchKernelGGL((k_conv3x3<128, 32, 4, 1, 1, 1, 1>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(256), lds, s, a);
+            const size_t lds = conv_lds_bytes<128, 32>();
+            hipLaunchKernelGGL((k_conv3x3<128, 32, 8, 1, 1, 1, 1>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(CONV_THREADS), lds, s, a);
         }
         const int F = HW * 8;
         hipLaunchKernelGGL(k_dense1, dim3((n + 7) / 8), dim3(128), (size_t)8 * F * 4, s, pfeat, f32["p.d1.w"], f32["p.d1.scale"],
@@ -505,8 +278,8 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->pd1 = e->dalloc<float>((size_t)cfg.n_games * 128); e->vd1 = e->dalloc<float>((size_t)cfg.n_games * 128);
     if (!e->X || !e->Aa || !e->Hh || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1) { *err = "hipMalloc failed"; delete e; return nullptr; }
     // dynamic LDS above 64 KB needs the attribute
-    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 4, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 4, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 8, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 
