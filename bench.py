@@ -114,7 +114,7 @@ def main():
     eng.timing_reset(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-    delta = np.array([int(s1["game_stats"][1] - s0["game_stats"][1]), int(s1["game_stats"][2] - s0["game_stats"][2]),
+    delta = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]),
                       s1["evals"] - s0["evals"], s1["sims"] - s0["sims"]], np.int64)
     total = reduce_stats(delta, world)                      # the one collective of the path: counters only
     positions, games, evals, sims = (int(x) for x in total)

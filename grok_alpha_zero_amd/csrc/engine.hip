@@ -38,9 +38,9 @@ template <class G> GAZ_KERNEL k_reset_games(DevParams<G> E, const int32_t* slots
     if (g < 0 || g >= E.n_games) return;
     GameState<G>& gs = E.games[g];
     const uint32_t seq = gs.game_seq + ((gs.phase == PH_NEW_GAME && gs.n_evals == 0) ? 0u : 1u);
-    const uint64_t ne = gs.n_evals, ns = gs.n_sims;
+    const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies;
     memset(&gs, 0, sizeof(gs));
-    gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns;
+    gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np;
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
@@ -80,6 +80,7 @@ template <class G> GAZ_KERNEL k_count(DevParams<G> E, int32_t* out) {   // out[0
     if (gs.pend_kind != PEND_NONE) atomic_add(&out[1], 1);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)gs.n_evals);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 4), (unsigned long long)gs.n_sims);
+    atomic_add(reinterpret_cast<unsigned long long*>(out + 6), (unsigned long long)gs.n_plies);
 }
 
 // ------------------------------------------------------------------------------------------ engine
@@ -103,7 +104,7 @@ struct gaz_engine {
     virtual int evaluate(const int8_t*, int, float*, float*, int, double*) = 0;
     virtual int record_layout(gaz_record_layout*) = 0;
     virtual int drain(void* out, int max_records, int32_t* n_out) = 0;
-    virtual int get_stats(uint64_t out[8]) = 0;
+    virtual int get_stats(uint64_t out[16]) = 0;
     virtual int synchronize() = 0;
     virtual int timing_reset(int enable) = 0;
     virtual int timing_get(double*, double*, double*, int64_t*, int64_t*) = 0;
@@ -158,6 +159,7 @@ template <class G> struct EngineT : gaz_engine {
         }
         E.nodes_per_tree = npt;
         E.ring_cap = cfg.ring_capacity;
+        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 32;
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
@@ -361,13 +363,15 @@ template <class G> struct EngineT : gaz_engine {
         return check_device_error();
     }
 
-    int get_stats(uint64_t out[8]) override {
+    int get_stats(uint64_t out[16]) override {
+        for (int i = 0; i < 16; ++i) out[i] = 0;
         int32_t c[8];
         if (counts(c)) return 1;
         unsigned long long s[8];
         HIP_OK(hipMemcpy(s, E.stats, sizeof(s), hipMemcpyDeviceToHost));
         for (int i = 0; i < 6; ++i) out[i] = s[i];
-        memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8);
+        memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
+        out[9] = (uint64_t)n_waves_total;
         return check_device_error();
     }
 
@@ -430,7 +434,7 @@ int gaz_engine_write_outputs(gaz_engine* h, const float* p, const float* v) { re
 int gaz_engine_evaluate(gaz_engine* h, const int8_t* in, int32_t n, float* p, float* v, int32_t repeats, double* ms) { return h->evaluate(in, n, p, v, repeats, ms); }
 int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* o) { return h->record_layout(o); }
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out) { return h->drain(out, max_records, n_out); }
-int gaz_engine_get_stats(gaz_engine* h, uint64_t out[8]) { return h->get_stats(out); }
+int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]) { return h->get_stats(out); }
 int gaz_engine_synchronize(gaz_engine* h) { return h->synchronize(); }
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable) { return h->timing_reset(enable); }
 int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }

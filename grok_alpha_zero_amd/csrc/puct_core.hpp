@@ -33,7 +33,7 @@ struct PathEnt { int32_t node; int32_t slot; };
 template <class G> struct DevParams {
     // configuration
     int32_t n_games, run_iterations, max_actions, explore_first, explore_second;
-    int32_t create_new_root, sync_moves, nodes_per_tree, ring_cap, use_dirichlet;
+    int32_t create_new_root, sync_moves, nodes_per_tree, ring_cap, use_dirichlet, max_tree_sims;
     double c_init, c_base, alpha, eps;
     float one_minus_eps;
     uint32_t key0, key1, slot_offset;
@@ -552,6 +552,7 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
         wave_sync();
     }
 
+    int tree_only = 0;   // simulations completed in this launch without an evaluation
     for (int guard = 0; guard < 100000; ++guard) {
         const int phase = uni(gs.phase);
         if (phase == PH_NEW_GAME) {                                    // Game.__init__ + Self_Play.__init__ (Self_Play.py:37-57)
@@ -601,6 +602,50 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
                 for (int base = 0; base < na; base += WAVE) { int i = base + lane_id(); zero |= ballot(i < na && r.N()[i] == 0u); }
                 if (!zero) { if (lane_id() == 0) gs.fully_visited = 1; wave_sync(); }
             }
+            if (uni(gs.fully_visited) && (uni((int)r.hdr()->flags) & NF_TERMINAL_PARENT)) {
+                // Root with a terminal move available (MCTS.py:200-208 at depth 0): every remaining simulation is
+                // "pick a terminal child, back up 1 (win) or 0 (draw)" and touches only the root's arrays, so up to 64
+                // of them run at once, one RNG event per lane.  f32 adds of 1.0 onto integral W are exact, so
+                // W += count equals the reference's sequence of += 1.
+                const int nch = uni((int)r.hdr()->n_children);
+                int n_cand = 0, n_win = 0;
+                for (int base = 0; base < nch; base += WAVE) {
+                    int i = base + lane_id();
+                    uint64_t m = ballot(i < nch && r.child()[i] == CHILD_LEAF_WIN);
+                    if (i < nch && r.child()[i] == CHILD_LEAF_WIN) S.sact[n_win + popcll(m & ((1ull << lane_id()) - 1ull))] = (uint8_t)i;
+                    n_win += popcll(m);
+                }
+                uint64_t anypos = 0;
+                for (int base = 0; base < nch; base += WAVE) { int i = base + lane_id(); anypos |= ballot(i < nch && r.W()[i] > 0.0f); }
+                const bool wins_only = anypos != 0;
+                if (wins_only) n_cand = n_win;
+                else { for (int i = lane_id(); i < nch; i += WAVE) S.sact[i] = (uint8_t)i; n_cand = nch; }
+                wave_sync();
+                const int remaining = uni(gs.iter_limit) - uni(gs.sims_done);
+                const int chunk = remaining < WAVE ? remaining : WAVE;
+                int my_slot = -1;
+                if (lane_id() < chunk) {
+                    det::Event e = make_event(E, g, gs, ts, t, det::P_TERMINAL_PICK);
+                    e.event += (uint32_t)lane_id();
+                    my_slot = S.sact[det::pick(e, (uint32_t)n_cand)];
+                }
+                for (int c = 0; c < n_cand; ++c) {
+                    const int slot = S.sact[c];
+                    const int cnt = popcll(ballot(my_slot == slot));
+                    if (lane_id() == 0 && cnt) {
+                        if (r.child()[slot] == CHILD_LEAF_WIN) r.W()[slot] = r.W()[slot] + (float)cnt;
+                        r.N()[slot] = r.N()[slot] + (uint32_t)cnt;
+                    }
+                }
+                if (lane_id() == 0) {
+                    ts.root_visits += (uint64_t)chunk; ts.event += (uint32_t)chunk;
+                    gs.sims_done += chunk; gs.n_sims += (uint64_t)chunk;
+                }
+                wave_sync();
+                continue;
+            }
+            if (tree_only >= E.max_tree_sims) return;                  // bound the launch's tail; resume next wave
+            tree_only++;
             int node, depth; bool leaf_win = false; int kind;
             if (!uni(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
             else kind = puct_select<G>(E, g, gs, ts, t, S, node, depth, leaf_win);
@@ -637,7 +682,7 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
                 gs.board[cell] = (int8_t)mover;
                 gs.hist[ply] = (uint8_t)action;
                 rec[RL::OFF_ACT + ply] = (uint8_t)action;
-                gs.n_hist = ply + 1; gs.next_player = -mover; gs.host_move = -1;
+                gs.n_hist = ply + 1; gs.next_player = -mover; gs.host_move = -1; gs.n_plies += 1;
             }
             wave_sync();
             bool ended = winner != RUNNING;

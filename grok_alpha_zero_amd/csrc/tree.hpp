@@ -85,7 +85,7 @@ template <class G> struct GameState {
     int32_t host_move;         // sync mode: host override, -1 = use chosen
     int32_t winner;
     uint32_t move_evals;       // evaluator calls during the current run()
-    uint64_t n_evals, n_sims;  // lifetime counters of this slot
+    uint64_t n_evals, n_sims, n_plies;  // lifetime counters of this slot (n_plies = positions played)
 };
 
 // per-game record of the game in progress (and of finished games in the ring); see engine.hip for the

@@ -59,6 +59,8 @@ typedef struct {
     /* ResNet (evaluator == GAZ_EVAL_RESNET): trunk of `net_blocks` pre-activation blocks x `net_filters` */
     int32_t net_blocks, net_filters;
     int32_t policy_is_logits;     /* 1: evaluator emits raw logits (Gumbel), 0: probabilities (softmax) */
+    int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 32);
+                                       scheduling only — results do not depend on it */
 } gaz_engine_config;
 
 typedef struct {
@@ -102,7 +104,8 @@ int gaz_engine_evaluate(gaz_engine* h, const int8_t* inputs, int32_t n, float* p
 
 int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* out);
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out);
-int gaz_engine_get_stats(gaz_engine* h, uint64_t out[8]);   /* [0..5] game_stats, [6] evaluator calls, [7] simulations */
+int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]);  /* [0..5] game_stats, [6] evaluator calls, [7] simulations,
+                                                               [8] plies played (= positions, incl. games in progress), [9] waves launched */
 int gaz_engine_synchronize(gaz_engine* h);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
