@@ -1,0 +1,153 @@
+"""run_self_play — the reference's self-play driver surface on top of the MI355X engine.
+
+Mirrors `run_self_play(game_class, configs, folder_path, per_process_wait_time)` (Self_Play.py:259-413) and what
+`Self_Play.play()` appends to the replay file (Self_Play.py:159-208): per finished game and per augmentation k,
+datasets `boards_k` (board dtype), `policies_k` (f32), `values_k` (f32) with `values = 0.5 * (z + q)`, and the
+`game_stats` u32[6] counters [max_len, total_actions, n_games, wins(-1), draws, wins(+1)].
+
+Instead of N worker processes + a shared-memory inference server (Self_Play.py:334-400, Client_Server.py) all games run
+concurrently on the GPU; `num_workers` therefore only bounds nothing here — the concurrency is `n_games`.
+
+Storage: the reference writes HDF5 through h5py.  h5py is not installed in this image, so `ReplayStore` uses h5py when
+it is importable and otherwise an .npz directory with the SAME dataset names / dtypes / shapes (SURVEY.md §8f ranks the
+libhdf5 writer as the next row).
+"""
+import os
+
+import numpy as np
+
+from .engine import EVAL_HASH, EVAL_RESNET, SelfPlayEngine
+
+
+class ReplayStore:
+    """`Self_Play_Data.h5` look-alike: game_stats + boards_k / policies_k / values_k (Self_Play.py:178-208)."""
+
+    def __init__(self, folder_path):
+        self.folder = folder_path
+        try:
+            import h5py  # noqa: F401
+            self.h5 = True
+        except ImportError:
+            self.h5 = False
+        self.path = os.path.join(folder_path, "Self_Play_Data.h5" if self.h5 else "Self_Play_Data.npzdir")
+
+    def exists(self):
+        return os.path.exists(self.path)
+
+    def create(self):
+        os.makedirs(self.folder, exist_ok=True)
+        if self.h5:
+            import h5py
+            with h5py.File(self.path, "w", libver="latest") as f:      # Connect4/main.py:83-86
+                f.create_dataset("game_stats", maxshape=(6,), dtype=np.uint32, data=np.zeros(6, np.uint32))
+        else:
+            os.makedirs(self.path, exist_ok=True)
+            np.save(os.path.join(self.path, "game_stats.npy"), np.zeros(6, np.uint32))
+
+    def game_stats(self):
+        if self.h5:
+            import h5py
+            with h5py.File(self.path, "r") as f:
+                return np.array(f["game_stats"])
+        return np.load(os.path.join(self.path, "game_stats.npy"))
+
+    def n_datasets(self):
+        if self.h5:
+            import h5py
+            with h5py.File(self.path, "r") as f:
+                return len(f.keys()) - 1
+        return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
+
+    def append_game(self, boards_aug, policies_aug, values_aug, game_length, n_positions, winner):
+        """One finished game: arrays [n_aug, T, ...] (Self_Play.py:174-208)."""
+        stats = self.game_stats().astype(np.uint32)
+        stats[0] = max(int(stats[0]), game_length)
+        stats[1] += n_positions
+        stats[2] += 1
+        stats[winner + 4] += 1
+        k0 = self.n_datasets() // 3                                   # dataset_name = (len(keys) - 1) // 3
+        if self.h5:
+            import h5py
+            with h5py.File(self.path, "r+") as f:
+                f["game_stats"][:] = stats
+                for inc in range(policies_aug.shape[0]):
+                    f.create_dataset(f"boards_{k0 + inc}", maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype, data=boards_aug[inc])
+                    f.create_dataset(f"policies_{k0 + inc}", maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32, data=policies_aug[inc])
+                    f.create_dataset(f"values_{k0 + inc}", maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32, data=values_aug[inc])
+        else:
+            np.save(os.path.join(self.path, "game_stats.npy"), stats)
+            for inc in range(policies_aug.shape[0]):
+                np.save(os.path.join(self.path, f"boards_{k0 + inc}.npy"), boards_aug[inc])
+                np.save(os.path.join(self.path, f"policies_{k0 + inc}.npy"), policies_aug[inc].astype(np.float32))
+                np.save(os.path.join(self.path, f"values_{k0 + inc}.npy"), values_aug[inc].astype(np.float32))
+
+    def read(self, name):
+        if self.h5:
+            import h5py
+            with h5py.File(self.path, "r") as f:
+                return np.array(f[name])
+        return np.load(os.path.join(self.path, name + ".npy"))
+
+
+def record_to_samples(game_class, rec):
+    """Rebuild what Self_Play.play() collected for one finished game (Self_Play.py:80,114-127,159-175): input states by
+    replaying the moves through the Game plugin, improved policies, values = 0.5 (z + q), then augment_sample."""
+    game = game_class()
+    states = []
+    for idx in rec["actions"]:
+        states.append(np.array(game.get_input_state()).copy())
+        game.do_action(game_class.index_to_action(int(idx)) if hasattr(game_class, "index_to_action") else idx)
+    board_states = np.array(states, dtype=game.board.dtype)
+    policies = np.asarray(rec["policies"], np.float32)
+    values = np.asarray(rec["values"], np.float32).reshape(-1, 1)
+    aug_b, aug_p = game.augment_sample(board_states, policies)
+    aug_b, aug_p = np.asarray(aug_b), np.asarray(aug_p)
+    aug_v = np.repeat(values[None], aug_p.shape[0], axis=0)
+    return aug_b, aug_p, aug_v, len(game.action_history)
+
+
+def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
+                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None):
+    """Generate `games_per_generation - game_stats[2]` self-play games into `folder_path` (Self_Play.py:259-272).
+    `configs` = (build_config, train_config[, optimizer_config]).  `weights` = dict from net.export_engine_weights()
+    (generation > 0); generation 0 (folder name "0") plays with the synthetic evaluator like the reference's
+    session=None dummy (Self_Play.py:40, MCTS.py:237-241)."""
+    build_config, train_config = configs[0], configs[1]
+    store = ReplayStore(folder_path)
+    if not store.exists():
+        raise ValueError("Dataset file hasn't been created. Self play depends on that file!")     # Self_Play.py:264-265
+    games_left = int(train_config["games_per_generation"] - store.game_stats()[2])
+    if games_left <= 0:
+        return 0
+    if train_config.get("use_gumbel"):
+        raise NotImplementedError("the Gumbel search path is not in this library version")
+    generation = int(str(folder_path).rstrip("/").split("/")[-1])
+    name = getattr(game_class, "ENGINE_NAME", game_class.__name__)
+    use_net = generation > 0 and weights is not None
+    G = min(n_games, games_left)
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")                 # np.random.seed() from OS entropy (Self_Play.py:221)
+    eng = SelfPlayEngine(name, G, int(train_config["MCTS_iteration_limit"] * 1.5), train_config["max_actions"],
+                         train_config["num_explore_actions_first"], train_config["num_explore_actions_second"],
+                         train_config["c_puct_init"], train_config["dirichlet_alpha"], seed,
+                         create_new_root=train_config.get("create_new_root", False), slot_offset=slot_offset, device=device,
+                         evaluator=EVAL_RESNET if use_net else EVAL_HASH, hash_salt=hash_salt,
+                         net_blocks=build_config.get("num_resnet_layers", 0) if use_net else 0,
+                         net_filters=build_config.get("num_filters", 128), ring_capacity=max(4 * G, 64), lib_path=lib_path)
+    if use_net:
+        eng.load_weights(weights)
+    written = 0
+    try:
+        while written < games_left:
+            eng.run_waves(64)
+            for rec in eng.drain_finished():
+                if written >= games_left:
+                    break
+                aug_b, aug_p, aug_v, length = record_to_samples(game_class, rec)
+                store.append_game(aug_b, aug_p, aug_v, length, rec["T"], rec["winner"])
+                written += 1
+                if progress:
+                    progress(written, games_left)
+    finally:
+        eng.close()
+    return written

@@ -1,0 +1,147 @@
+"""CPU suite: host Game plugins (Game_Tester-style conformance, /root/reference/Game_Tester.py:9-576 restated as
+pytest) cross-checked against the oracle's C rules and the golden Self_Play outputs; run_self_play end to end on the
+emulation build; the multi-rank counter reduction under gloo (world size 2)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from grok_alpha_zero_amd.games import GAMES
+
+GID = {"TicTacToe": 0, "Connect4": 1, "Gomoku": 2}
+
+
+def _i8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int8))
+
+
+@pytest.mark.parametrize("name", ["TicTacToe", "Connect4", "Gomoku"])
+def test_game_plugin_conformance_random_playouts(oracle, name):
+    L = oracle.lib()
+    cls = GAMES[name]
+    rng = np.random.default_rng(GID[name])
+    for _ in range(30 if name != "Gomoku" else 6):
+        g = cls()
+        assert g.board.dtype == np.int8 and g.next_player == -1 and g.action_history == [] and len(g.policy_shape) == 1
+        cboard = np.zeros(g.board.size, np.int8)
+        hist = []
+        winner = -2
+        while winner == -2:
+            legal = g.get_legal_actions()
+            buf = (C.c_int * 256)()
+            k = L.gaz_api_legal_actions(GID[name], _i8(cboard), buf)
+            idx = [cls.action_to_index(a) for a in legal]
+            assert idx == list(buf[:k]) and len(set(idx)) == len(idx) and k > 0           # no duplicates, same order as the device rules
+            pol = rng.random(g.policy_shape[0]).astype(np.float32)
+            la, lp = cls.get_legal_actions_policy_MCTS(g.board, -g.next_player, np.array(g.action_history), pol.copy())
+            assert abs(float(np.sum(lp)) - 1.0) < 1e-5 and len(la) == k
+            a = legal[rng.integers(0, k)]
+            mover = g.next_player
+            # static vs instance do_action agree
+            b2 = cls.do_action_MCTS(g.board.copy(), a, mover)
+            g.do_action(a)
+            assert np.array_equal(b2, g.board) and g.next_player == -mover
+            ai = cls.action_to_index(a)
+            L.gaz_api_do_action(GID[name], _i8(cboard), ai, mover); hist.append(ai)
+            assert np.array_equal(cboard.reshape(g.board.shape), g.board)
+            winner = g.check_win()
+            assert winner == L.gaz_api_check_win(GID[name], _i8(cboard), mover, ai)
+            assert winner in (-2, 0, mover)                                                # the winner is the last mover
+            st = g.get_input_state()
+            out = np.zeros(st.size, np.int8); h = np.array(hist, np.int32)
+            L.gaz_api_input_state(GID[name], _i8(cboard), mover, h.ctypes.data_as(C.POINTER(C.c_int)), len(hist), _i8(out))
+            assert st.dtype == np.int8 and np.array_equal(st.reshape(-1), out)
+            if name == "Gomoku" and len(hist) >= 60:
+                break
+        if winner in (-1, 1):
+            assert winner == mover
+
+
+@pytest.mark.parametrize("fixture", ["ttt_puct_a", "c4_puct_a", "c4_puct_c", "gmk_puct_a"])
+def test_record_to_samples_reproduces_reference_replay_arrays(oracle, fixture):
+    """states / policies / values / augmentations rebuilt from an engine-style record == what the reference's
+    Self_Play.play() wrote to its HDF5 file (all augmentations)."""
+    from grok_alpha_zero_amd.self_play import record_to_samples
+    fx = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    cls = GAMES[str(fx["game"])]
+    rec = dict(actions=fx["actions"], policies=fx["policies"], values=fx["values"].reshape(-1), T=len(fx["actions"]))
+    b, p, v, length = record_to_samples(cls, rec)
+    assert b.shape[0] == int(fx["n_aug"]) and length == len(fx["actions"])
+    for k in range(int(fx["n_aug"])):
+        np.testing.assert_array_equal(b[k], fx[f"aug_boards_{k}"])
+        np.testing.assert_array_equal(p[k], fx[f"aug_policies_{k}"])
+        assert b[k].dtype == np.int8 and p[k].dtype == np.float32
+    np.testing.assert_array_equal(v[0], fx["values"])
+
+
+def test_run_self_play_on_emu(tmp_path, oracle):
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    train = dict(games_per_generation=5, MCTS_iteration_limit=20, max_actions=9, num_explore_actions_first=2,
+                 num_explore_actions_second=1, c_puct_init=1.25, dirichlet_alpha=1.0, use_gumbel=False)
+    n = run_self_play(GAMES["TicTacToe"], ({}, train), folder, n_games=3, seed=11, hash_salt=4,
+                      lib_path=os.path.join(emu_dir, "libgaz_emu.so"))
+    assert n == 5
+    gs = store.game_stats()
+    assert gs[2] == 5 and gs[3] + gs[4] + gs[5] == 5 and gs[0] <= 9
+    assert store.n_datasets() == 5 * 8 * 3                                   # 8 augmentations x (boards, policies, values)
+    total = sum(store.read(f"boards_{k * 8}").shape[0] for k in range(5))
+    assert total == gs[1]
+    b0 = store.read("boards_0"); p0 = store.read("policies_0"); v0 = store.read("values_0")
+    assert b0.dtype == np.int8 and b0.shape[1:] == (3, 3, 2) and p0.shape[1] == 9 and v0.shape[1] == 1
+    assert np.allclose(p0.sum(1), 1.0, atol=1e-6) and np.all(np.abs(v0) <= 1.0)
+    # resuming a finished generation does nothing (Self_Play.py:267-272)
+    assert run_self_play(GAMES["TicTacToe"], ({}, train), folder, n_games=3, seed=11,
+                         lib_path=os.path.join(emu_dir, "libgaz_emu.so")) == 0
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from grok_alpha_zero_amd.engine import SelfPlayEngine
+from grok_alpha_zero_amd.parallel import reduce_stats, shard_slots
+G = 3
+eng = SelfPlayEngine("TicTacToe", G, 20, 9, 2, 1, 1.25, 1.0, seed=5, hash_salt=2, slot_offset=rank * G, lib_path=sys.argv[2])
+recs = []
+while len({r["slot"] for r in recs if r["game_seq"] == 0}) < G:
+    eng.run_waves(32); recs += eng.drain_finished()
+first = sorted((r["slot"], r["T"], r["winner"], r["actions"].tolist()) for r in recs if r["game_seq"] == 0)
+assert [s for s, *_ in first] == shard_slots(G, rank).tolist()
+local = np.array([max(t for _, t, _, _ in first), sum(t for _, t, _, _ in first), len(first)], np.int64)
+tot = reduce_stats(local, world, max_fields=(0,))
+np.save(os.path.join(sys.argv[3], f"rank{rank}.npy"), np.array([repr(first), tot.tolist()], dtype=object), allow_pickle=True)
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharding_and_counter_reduce_gloo(tmp_path, oracle):
+    """N > 1 path on CPU: two processes (gloo), each owning its shard of global slots; per-game results are keyed by
+    the GLOBAL slot (so equal to a single-process run of the same slots) and the only collective reduces counters."""
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    emu = os.path.join(emu_dir, "libgaz_emu.so")
+    script = tmp_path / "worker.py"; script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, emu, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    out = [np.load(tmp_path / f"rank{r}.npy", allow_pickle=True) for r in range(2)]
+    assert out[0][1] == out[1][1]                                            # both ranks hold the same reduced counters
+    games = eval(out[0][0]) + eval(out[1][0])
+    assert [s for s, *_ in games] == list(range(6))
+    for slot, T, winner, actions in games:                                  # independent of the number of ranks
+        o = oracle.selfplay_game("TicTacToe", 20, 9, 2, 1, 1.25, 1.0, 5, slot, 0, hash_salt=2)
+        assert o["T"] == T and o["winner"] == winner and o["actions"].tolist() == actions
+    tot = out[0][1]
+    assert tot[0] == max(T for _, T, _, _ in games) and tot[1] == sum(T for _, T, _, _ in games) and tot[2] == 6
