@@ -10,9 +10,11 @@
 //     halo drags in are never selected, so nothing needs to be zero-filled);
 //   * the per-tap weight slice [Cout][Cin] (32 KB) is double-buffered in LDS: the DMA of tap t+1 is in flight
 //     while tap t multiplies, one barrier per tap;
-//   * both images are XOR-swizzled in 16-byte slots (slot ^= row & 15) by permuting the per-lane SOURCE
-//     address of the DMA (the LDS side of a DMA is lane-linear), so every ds_read_b128 fragment read is
-//     conflict-free; fragments are register double-buffered across k-steps;
+//   * the activation image is XOR-swizzled in 16-byte slots (slot ^= row & 15) by permuting the per-lane SOURCE
+//     address of the DMA (the LDS side of a DMA is lane-linear); the weights are pre-arranged on the host in
+//     fragment order [tap][k-step][k-half][cout][8] so their DMA is a straight copy and every fragment read is
+//     base + compile-time offset; both give conflict-free ds_read_b128; masked rows read a zero row instead of
+//     being zeroed in registers; fragments are register double-buffered across k-steps;
 //   * epilogue: accumulators -> fp32 LDS tile -> per-thread 16-byte channel groups: folded BN scale/shift,
 //     residual add, activation, and (for the pre-activation blocks) a second output relu(bn_next(x)) — whole
 //     256-byte rows per 16 lanes, dwordx4 stores.
@@ -37,7 +39,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 
 struct ConvArgs {
     const bf16_t* in;        // [M][CIN] NHWC rows
-    const bf16_t* wgt;       // [9][BN][CIN]
+    const bf16_t* wgt;       // [9][CIN/16][2][BN][8]: fragment order (k = ks*16 + half*8 + j), see arrange_conv_weights()
     const float* scaleA;     // [BN] or null (=1)
     const float* shiftA;     // [BN] or null (=0)
     const bf16_t* res;       // [M][BN] residual or null (may alias out1)
@@ -50,25 +52,34 @@ struct ConvArgs {
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft;
     float* p_feat; float* v_feat;
     int M, H, W;
+    int dbg;                 // timing experiments only (GAZ_CONV_DBG): 1 = no weight DMA after tap 0, 2 = no epilogue, 4 = no MFMA
 };
 
-constexpr int CONV_BM = 256;
 constexpr int CONV_HALO_MAX = 16;           // W + 1 <= 16
-constexpr int CONV_THREADS = 512;
+// LDS bytes of one workgroup: activation image (BM + halo rows + one zero row) + two weight slices of CIN/KSPLIT channels
+template <int CIN, int BN, int BM, int KSPLIT> constexpr size_t conv_lds_bytes() {
+    return (size_t)((BM + 2 * CONV_HALO_MAX + 1) * (CIN / 8) + 2 * BN * (CIN / 8) / KSPLIT) * 16;
+}
 
-template <int CIN, int BN> constexpr size_t conv_lds_bytes() {
-    return (size_t)((CONV_BM + 2 * CONV_HALO_MAX) * (CIN / 8) + 2 * BN * (CIN / 8)) * 16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {     // v_cvt_pk_bf16_f32 (round to nearest even)
+    bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return *reinterpret_cast<unsigned*>(&v);
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int CIN, int BN, int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
-    static_assert(WM * WN == 8 && WM * TM * 32 == CONV_BM && WN * TN * 32 == BN, "tile shape");
+// BM rows per workgroup, WM x WN waves each owning TM x TN MFMA tiles of 32x32; the weight stream is cut into
+// 9 * KSPLIT slices of CIN / KSPLIT input channels.  OCC = workgroups per CU the LDS budget is sized for.
+template <int CIN, int BN, int BM, int WM, int WN, int TM, int TN, int KSPLIT, int OCC, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3x3(ConvArgs a) {
+    constexpr int CONV_BM = BM, CONV_THREADS = WM * WN * 64;
+    static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int SLOTS = CIN / 8;                 // 16-byte slots per row (16 for CIN = 128)
     static_assert(SLOTS == 16, "swizzle below assumes 16 slots per row");
-    constexpr int AROWS = CONV_BM + 2 * CONV_HALO_MAX;
-    constexpr int BSL = BN * SLOTS;                // slots per weight slice
+    constexpr int AROWS = BM + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1;
+    constexpr int KSS = CIN / 16 / KSPLIT;         // k-steps per weight slice
+    constexpr int BSL = BN * SLOTS / KSPLIT;       // 16-byte units per weight slice
     extern __shared__ uint4 lds[];
     uint4* As = lds;
     uint4* Bs = lds + AROWS * SLOTS;               // two slices of BSL slots
@@ -90,11 +101,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
         gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);     // rows outside the tensor are never selected
         __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
     }
-    // weight slice of tap 0 -> Bs[0]
-    for (int base = wave * 64; base < BSL; base += CONV_THREADS) {
-        const int i = base + lane, n = i >> 4, sp = i & 15;
-        __builtin_amdgcn_global_load_lds((const void*)(w4 + n * SLOTS + (sp ^ (n & 15))), (lds_ptr_t)(Bs + base), 16, 0, 0);
-    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+    // weight slice of tap 0 -> Bs[0] (already in fragment order: straight copy)
+    for (int base = wave * 64; base < BSL; base += CONV_THREADS)
+        __builtin_amdgcn_global_load_lds((const void*)(w4 + base + lane), (lds_ptr_t)(Bs + base), 16, 0, 0);
 
     // ---- per-lane geometry of the TM row tiles this wave owns
     int lrow[TM]; unsigned vmask[TM];
@@ -112,12 +122,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
         }
         vmask[tm] = m;
     }
-    int bbase[TN], bxor[TN];
+    int bbase[TN];                                  // unit index of (ks = 0, half = lhi, n) in a slice
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = (wn * TN + tn) * 32 + l31;
-        bbase[tn] = n * SLOTS; bxor[tn] = n & 15;
-    }
+    for (int tn = 0; tn < TN; ++tn) bbase[tn] = lhi * BN + (wn * TN + tn) * 32 + l31;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -128,56 +135,55 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
 
     __syncthreads();                                // image + slice 0 have landed (the barrier drains the DMA queue)
 
-    for (int tap = 0; tap < 9; ++tap) {
-        const uint4* Bc = Bs + (tap & 1) * BSL;
-        if (tap + 1 < 9) {                          // DMA of the next slice into the other buffer, in flight during the MFMAs
-            uint4* Bn = Bs + ((tap + 1) & 1) * BSL;
-            const uint4* wsrc = w4 + (size_t)(tap + 1) * BSL;
-            for (int base = wave * 64; base < BSL; base += CONV_THREADS) {
-                const int i = base + lane, n = i >> 4, sp = i & 15;
-                __builtin_amdgcn_global_load_lds((const void*)(wsrc + n * SLOTS + (sp ^ (n & 15))), (lds_ptr_t)(Bn + base), 16, 0, 0);
-            }
+    for (int sl = 0; sl < 9 * KSPLIT; ++sl) {
+        const int tap = sl / KSPLIT, ks0 = (sl % KSPLIT) * KSS;
+        const uint4* Bc = Bs + (sl & 1) * BSL;
+        if (sl + 1 < 9 * KSPLIT && !(a.dbg & 1)) {  // DMA of the next slice into the other buffer, in flight during the MFMAs
+            uint4* Bn = Bs + ((sl + 1) & 1) * BSL;
+            const uint4* wsrc = w4 + (size_t)(sl + 1) * BSL;
+            for (int base = wave * 64; base < BSL; base += CONV_THREADS)
+                __builtin_amdgcn_global_load_lds((const void*)(wsrc + base + lane), (lds_ptr_t)(Bn + base), 16, 0, 0);
         }
         const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
-        int abase[TM], axor[TM]; bool aval[TM];
+        int abase[TM], axor[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const int ar = lrow[tm] + halo + off;
-            abase[tm] = ar * SLOTS; axor[tm] = ar & 15; aval[tm] = (vmask[tm] >> tap) & 1u;
+            const bool ok = (vmask[tm] >> tap) & 1u;
+            const int ar = ok ? lrow[tm] + halo + off : ZROW;       // masked taps read the zero row
+            abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
         }
         // software pipeline over the k-steps: fragments of step ks+1 are in flight while step ks multiplies
         uint4 afr[2][TM], bfr[2][TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + ((ks0 * 2 + lhi) ^ axor[tm])];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bfr[0][tn] = Bc[bbase[tn] + (lhi ^ bxor[tn])];
+        for (int tn = 0; tn < TN; ++tn) bfr[0][tn] = Bc[bbase[tn]];
 #pragma unroll
-        for (int ks = 0; ks < CIN / 16; ++ks) {
+        for (int ks = 0; ks < KSS; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < CIN / 16) {
+            if (ks + 1 < KSS) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks0 + ks + 1) * 2 + lhi) ^ axor[tm])];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bfr[nxt][tn] = Bc[bbase[tn] + (((ks + 1) * 2 + lhi) ^ bxor[tn])];
+                for (int tn = 0; tn < TN; ++tn) bfr[nxt][tn] = Bc[bbase[tn] + (ks + 1) * 2 * BN];
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                uint4 v = afr[cur][tm];
-                if (!aval[tm]) v = make_uint4(0, 0, 0, 0);
-                const bf16x8 af = *reinterpret_cast<bf16x8*>(&v);
+                const bf16x8 af = *reinterpret_cast<bf16x8*>(&afr[cur][tm]);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
+                    if (!(a.dbg & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
             }
         }
         __syncthreads();                            // slice tap+1 landed; everyone is done reading slice tap
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (a.dbg & 2) return;
     if (EPI == 0) {
         constexpr int CT = BN + 4;
-        float* Ct = reinterpret_cast<float*>(lds);  // [256][BN + 4] fp32 over the (now idle) image + slices
-        static_assert((size_t)CONV_BM * CT * 4 <= conv_lds_bytes<CIN, BN>(), "epilogue tile must fit");
+        float* Ct = reinterpret_cast<float*>(lds);  // [BM][BN + 4] fp32 over the (now idle) image + slices
+        static_assert((size_t)BM * CT * 4 <= conv_lds_bytes<CIN, BN, BM, KSPLIT>(), "epilogue tile must fit");
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -207,23 +213,25 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
             const size_t o = (size_t)gr * BN + chunk * 8;
             if (a.res) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(a.res + o);
-                const bf16_t* rb = reinterpret_cast<const bf16_t*>(&rv);
+                const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += bf2f(rb[j]);
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] += __uint_as_float(rw[j] << 16);
+                    v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
+                }
             }
             if (a.act1 == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
             }
-            bf16_t o1[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = f2bf(v[j]);
-            *reinterpret_cast<uint4*>(a.out1 + o) = *reinterpret_cast<const uint4*>(o1);
+            *reinterpret_cast<uint4*>(a.out1 + o) =
+                make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
             if (a.out2) {
-                bf16_t o2[8];
+                float w[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o2[j] = f2bf(fmaxf(v[j] * sB[j] + tB[j], 0.0f));
-                *reinterpret_cast<uint4*>(a.out2 + o) = *reinterpret_cast<const uint4*>(o2);
+                for (int j = 0; j < 8; ++j) w[j] = fmaxf(v[j] * sB[j] + tB[j], 0.0f);
+                *reinterpret_cast<uint4*>(a.out2 + o) =
+                    make_uint4(pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]), pack_bf16(w[4], w[5]), pack_bf16(w[6], w[7]));
             }
         }
     } else {
@@ -247,6 +255,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv3x3(ConvArgs a) {
                 }
             }
     }
+}
+
+// Host: [9][cout][cin] (export order) -> [9][cin/16][2][cout][8] (MFMA B-fragment order).
+inline void arrange_conv_weights(const float* src, int cout, int cin, bf16_t* dst, bf16_t (*cvt)(float)) {
+    for (int tap = 0; tap < 9; ++tap)
+        for (int n = 0; n < cout; ++n)
+            for (int k = 0; k < cin; ++k) {
+                const int ks = k / 16, half = (k % 16) / 8, j = k % 8;
+                dst[((((size_t)tap * (cin / 16) + ks) * 2 + half) * cout + n) * 8 + j] = cvt(src[((size_t)tap * cout + n) * cin + k]);
+            }
 }
 
 }  // namespace gaz

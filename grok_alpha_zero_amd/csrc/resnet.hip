@@ -182,10 +182,11 @@ struct ResNetEvaluator : Evaluator {
             float* d = dalloc<float>(numel); if (!d) { *err = "hipMalloc"; return false; }
             hipMemcpy(d, g->data, numel * 4, hipMemcpyHostToDevice); f32[name] = d; return true;
         };
-        auto up_b16 = [&](const std::string& name, int64_t numel) -> bool {
+        auto up_b16 = [&](const std::string& name, int64_t numel) -> bool {      // conv weights [9][cout][cin] -> fragment order
             const gaz_tensor* g = need(name, numel); if (!g) return false;
             std::vector<bf16_t> h(numel);
-            for (int64_t i = 0; i < numel; ++i) h[i] = f2bf_host(g->data[i]);
+            const int cin = 128, cout = (int)(numel / (9 * cin));
+            arrange_conv_weights(g->data, cout, cin, h.data(), f2bf_host);
             bf16_t* d = dalloc<bf16_t>(numel); if (!d) { *err = "hipMalloc"; return false; }
             hipMemcpy(d, h.data(), numel * 2, hipMemcpyHostToDevice); b16[name] = d; return true;
         };
@@ -214,8 +215,15 @@ struct ResNetEvaluator : Evaluator {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1;
         a.scaleB = sB; a.shiftB = tB; a.out2 = out2; a.M = M; a.H = H; a.W = W;
-        const size_t lds = conv_lds_bytes<128, 128>();
-        hipLaunchKernelGGL((k_conv3x3<128, 128, 4, 2, 2, 2, 0>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(CONV_THREADS), lds, s, a);
+        { const char* d = getenv("GAZ_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
+        static const int variant = getenv("GAZ_CONV_VARIANT") ? atoi(getenv("GAZ_CONV_VARIANT")) : 1;
+        if (variant == 0) {          // 256 rows / 512 threads / whole-tap slices, one workgroup per CU
+            const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
+            hipLaunchKernelGGL((k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), dim3((M + 255) / 256), dim3(512), lds, s, a);
+        } else {                     // 128 rows / 256 threads / half-tap slices, two workgroups per CU overlap their phases
+            const size_t lds = conv_lds_bytes<128, 128, 128, 2>();
+            hipLaunchKernelGGL((k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), dim3((M + 127) / 128), dim3(256), lds, s, a);
+        }
         n_trunk_launches++;
     }
 
@@ -242,8 +250,8 @@ struct ResNetEvaluator : Evaluator {
             a.in = X; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
             a.p_fs = f32["p.bn0.scale"]; a.p_ft = f32["p.bn0.shift"]; a.v_fs = f32["v.bn0.scale"]; a.v_ft = f32["v.bn0.shift"];
             a.p_feat = pfeat; a.v_feat = vfeat;
-            const size_t lds = conv_lds_bytes<128, 32>();
-            hipLaunchKernelGGL((k_conv3x3<128, 32, 8, 1, 1, 1, 1>), dim3((M + CONV_BM - 1) / CONV_BM), dim3(CONV_THREADS), lds, s, a);
+            const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
+            hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), dim3((M + 255) / 256), dim3(512), lds, s, a);
         }
         const int F = HW * 8;
         hipLaunchKernelGGL(k_dense1, dim3((n + 7) / 8), dim3(128), (size_t)8 * F * 4, s, pfeat, f32["p.d1.w"], f32["p.d1.scale"],
@@ -278,8 +286,9 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->pd1 = e->dalloc<float>((size_t)cfg.n_games * 128); e->vd1 = e->dalloc<float>((size_t)cfg.n_games * 128);
     if (!e->X || !e->Aa || !e->Hh || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1) { *err = "hipMalloc failed"; delete e; return nullptr; }
     // dynamic LDS above 64 KB needs the attribute
-    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 4, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 8, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 
