@@ -75,6 +75,9 @@ def lib():
         L.gaz_selfplay_game.argtypes = [C.POINTER(SPConfig), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SPRecord)]
         L.gaz_selfplay_game.restype = C.c_int
         L.gaz_oracle_set_libm.argtypes = [C.c_int]
+        L.gaz_selfplay_game_gumbel.argtypes = [C.POINTER(SPConfig), C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(SPRecord)]
+        L.gaz_selfplay_game_gumbel.restype = C.c_int
         L.gaz_puct_best_index.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int,
                                           C.c_uint64, C.c_double, C.c_double, C.c_int]
         L.gaz_puct_best_index.restype = C.c_int
@@ -153,9 +156,16 @@ def hash_eval(state_i8, A, salt):
 
 
 # ---------------------------------------------------------------- self-play of one game
+def selfplay_game_gumbel(game, iteration_limit, max_actions, m, c_visit, c_scale, seed, slot=0, game_seq=0, evaluator=None,
+                         hash_salt=0, use_libm=False):
+    """One Gumbel self-play game (MCTS_Gumbel.run(iteration_limit) per move, gumbel noise on, softmax policy head)."""
+    return selfplay_game(game, iteration_limit, max_actions, 0, 0, 0.0, 0.0, seed, slot, game_seq, evaluator, hash_salt,
+                         use_libm=use_libm, gumbel=(m, c_visit, c_scale))
+
+
 def selfplay_game(game, run_iterations, max_actions, explore_first, explore_second, c_puct_init, dirichlet_alpha,
                   seed, slot=0, game_seq=0, evaluator=None, hash_salt=0, c_puct_base=19652.0, create_new_root=False,
-                  use_libm=False):
+                  use_libm=False, gumbel=None):
     """Play one PUCT self-play game with the oracle.  evaluator(state_i8[H,W,C]) -> (policy f32[A], value f32),
     or None for the built-in hash evaluator.  Returns a dict of numpy arrays (see gaz_sp_record)."""
     L = lib()
@@ -175,10 +185,16 @@ def selfplay_game(game, run_iterations, max_actions, explore_first, explore_seco
     cfg = SPConfig(gid, run_iterations, max_actions, explore_first, explore_second, c_puct_init, c_puct_base,
                    dirichlet_alpha, int(create_new_root))
     L.gaz_oracle_set_libm(int(use_libm))
+
+    def play(fn, ctxp):
+        if gumbel is None:
+            L.gaz_selfplay_game(C.byref(cfg), fn, ctxp, seed, slot, game_seq, C.byref(rec))
+        else:
+            L.gaz_selfplay_game_gumbel(C.byref(cfg), int(gumbel[0]), float(gumbel[1]), float(gumbel[2]), run_iterations, fn, ctxp,
+                                       seed, slot, game_seq, int(use_libm), C.byref(rec))
     if evaluator is None:
         ctx = HashEvalCtx(hash_salt, A)
-        fn = C.cast(L.gaz_hash_eval, C.c_void_p)
-        L.gaz_selfplay_game(C.byref(cfg), fn, C.cast(C.byref(ctx), C.c_void_p), seed, slot, game_seq, C.byref(rec))
+        play(C.cast(L.gaz_hash_eval, C.c_void_p), C.cast(C.byref(ctx), C.c_void_p))
     else:
         def cb(_ctx, state, n, pol, val):
             s = np.ctypeslib.as_array(state, shape=(n,)).reshape(H, W, Cc)
@@ -186,7 +202,7 @@ def selfplay_game(game, run_iterations, max_actions, explore_first, explore_seco
             np.ctypeslib.as_array(pol, shape=(A,))[:] = np.asarray(p, np.float32).reshape(-1)
             val[0] = float(v)
         fn = EVAL_FN(cb)
-        L.gaz_selfplay_game(C.byref(cfg), C.cast(fn, C.c_void_p), None, seed, slot, game_seq, C.byref(rec))
+        play(C.cast(fn, C.c_void_p), None)
     L.gaz_oracle_set_libm(0)
     T = rec.T
     out = {k: v[:T].copy() for k, v in arrs.items()}

@@ -36,6 +36,10 @@ typedef struct {
 int gaz_selfplay_game(const gaz_sp_config* cfg, gaz_eval_fn eval, void* ctx, uint64_t seed, uint32_t slot,
                       uint32_t game_seq, gaz_sp_record* rec);
 void gaz_oracle_set_libm(int on);
+/* Self_Play.play with use_gumbel = True: MCTS_Gumbel.run(iteration_limit) per move, fresh tree every move */
+int gaz_selfplay_game_gumbel(const gaz_sp_config* cfg, int m, double c_visit, double c_scale, int iteration_limit,
+                             gaz_eval_fn eval, void* ctx, uint64_t seed, uint32_t slot, uint32_t game_seq, int use_libm,
+                             gaz_sp_record* rec);
 #ifdef __cplusplus
 }
 #endif

@@ -42,3 +42,24 @@ def test_puct_selfplay_matches_reference(oracle, name, use_libm):
 
 def test_fixture_inventory():
     assert {"ttt_puct_a", "c4_puct_a", "c4_puct_c", "gmk_puct_a"} <= set(CASES)
+
+
+GUMBEL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_gumbel_*.npz")))
+
+
+@pytest.mark.parametrize("use_libm", [False, True], ids=["detmath", "libm"])
+@pytest.mark.parametrize("name", GUMBEL_CASES)
+def test_gumbel_selfplay_matches_reference(oracle, name, use_libm):
+    """MCTS_Gumbel (sequential halving, completed-Q, deterministic selection) + the use_gumbel branch of Self_Play."""
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    r = oracle.selfplay_game_gumbel(str(fx["game"]), int(fx["run_iterations"]), int(fx["max_actions"]), int(fx["m"]),
+                                    float(fx["c_visit"]), float(fx["c_scale"]), int(fx["seed"]), int(fx["slot"]),
+                                    int(fx["game_seq"]), hash_salt=int(fx["salt"]), use_libm=use_libm)
+    assert r["T"] == len(fx["actions"]) and r["total_evals"] == int(fx["evaluator_calls"])
+    for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "states", "policies"):
+        np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
+    np.testing.assert_array_equal(r["values"], fx["values"].reshape(-1))
+
+
+def test_gumbel_fixture_inventory():
+    assert {"ttt_gumbel_a", "c4_gumbel_a", "gmk_gumbel_a"} <= set(GUMBEL_CASES)

@@ -29,7 +29,7 @@ def action_to_index(game, action):
 
 
 def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore_second, c_puct_init, alpha,
-                      seed, slot, game_seq, salt, session=None):
+                      seed, slot, game_seq, salt, session=None, gumbel=None):
     """Run the reference's Self_Play.play() once; returns the fixture dict."""
     ref = ref_shim.load_reference()
     inj = ref_shim.activate(seed, slot, game_seq)
@@ -41,6 +41,8 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
                     "use_njit": False, "c_puct_init": c_puct_init, "dirichlet_alpha": alpha,
                     "max_actions": max_actions, "num_explore_actions_first": explore_first,
                     "num_explore_actions_second": explore_second}
+    if gumbel is not None:
+        train_config.update(use_gumbel=True, m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2])
     build_config = {}
     folder = f"/fake/{game}_{iteration_limit}_{seed}_{slot}_{game_seq}/1"
     ref_shim._FakeH5File.STORE.pop(folder + "/Self_Play_Data.h5", None)
@@ -74,6 +76,8 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
                actions=acts, root_N=rN, root_W=rW, root_P=rP, root_visits=rV,
                states=d["boards_0"].data, policies=d["policies_0"].data, values=d["values_0"].data,
                game_stats=d["game_stats"].data, n_aug=n_aug, evaluator_calls=sess.calls)
+    if gumbel is not None:
+        out.update(m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2], run_iterations=iteration_limit)
     for k in range(n_aug):
         out[f"aug_boards_{k}"] = d[f"boards_{k}"].data
         out[f"aug_policies_{k}"] = d[f"policies_{k}"].data
@@ -91,9 +95,25 @@ PUCT_CASES = [
 ]
 
 
+GUMBEL_CASES = [
+    # name, game, MCTS_iteration_limit, max_actions, m, c_visit, c_scale, seed, slot, seq, salt
+    ("ttt_gumbel_a", "TicTacToe", 16, 9, 4, 50.0, 2.0, 1234, 0, 0, 7),
+    ("c4_gumbel_a", "Connect4", 32, 42, 7, 50.0, 1.0, 1234, 0, 0, 11),        # BASELINE config 5: n = 32, m = 7
+    ("c4_gumbel_b", "Connect4", 32, 42, 7, 50.0, 1.0, 77, 9, 3, 5),
+    ("c4_gumbel_c", "Connect4", 64, 42, 4, 50.0, 1.0, 5, 2, 0, 3),
+    ("gmk_gumbel_a", "Gomoku", 48, 10, 16, 50.0, 1.0, 1234, 0, 0, 5),
+]
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     only = set(sys.argv[1:])
+    for name, game, it, max_actions, m, c_visit, c_scale, seed, slot, seq, salt in GUMBEL_CASES:
+        if only and name not in only:
+            continue
+        fx = ref_selfplay_puct(game, it, max_actions, 0, 0, 0.0, 0.0, seed, slot, seq, salt, gumbel=(m, c_visit, c_scale))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "stats", fx["game_stats"], "evals", fx["evaluator_calls"], flush=True)
     for name, *cfg in PUCT_CASES:
         if only and name not in only:
             continue
