@@ -6,6 +6,7 @@
 #include "../../include/gaz_engine.h"
 #include "rt.hpp"
 #include "puct_core.hpp"
+#include "gumbel_core.hpp"
 #include "evaluator.hpp"
 
 using namespace gaz;
@@ -20,6 +21,12 @@ template <class G> GAZ_KERNEL k_wave(DevParams<G> E) {
     GAZ_SHARED Scratch<G> S;
     const int g = block_id();
     if (g < E.n_games) game_step<G>(E, g, S);
+}
+
+template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E) {
+    GAZ_SHARED Scratch<G> S;
+    const int g = block_id();
+    if (g < E.n_games) g_game_step<G>(E, g, S);
 }
 
 template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
@@ -146,12 +153,17 @@ template <class G> struct EngineT : gaz_engine {
         memset(&E, 0, sizeof(E));
         const int n = cfg.n_games;
         if (n <= 0) return fail("n_games must be positive");
-        if (cfg.search != GAZ_SEARCH_PUCT) return fail("search: only GAZ_SEARCH_PUCT is built in this library version");
+        const bool gumbel = cfg.search == GAZ_SEARCH_GUMBEL;
+        if (cfg.search != GAZ_SEARCH_PUCT && !gumbel) return fail("unknown search id");
+        E.c_visit = cfg.c_visit; E.c_scale = cfg.c_scale; E.gumbel_m = cfg.gumbel_m;
+        if (gumbel && (cfg.gumbel_m < 2 || cfg.run_iterations < 1)) return fail("Gumbel search needs m >= 2 and run_iterations >= 1");
+        E.node_bytes = gumbel ? gumbel_node_bytes<G>() : NodeLayout<G>::SIZE;
         E.n_games = n; E.run_iterations = cfg.run_iterations; E.max_actions = cfg.max_actions;
         if (cfg.max_actions > G::MAXT || cfg.max_actions <= 0) return fail("max_actions out of range for this game");
         E.explore_first = cfg.num_explore_actions_first; E.explore_second = cfg.num_explore_actions_second;
         E.create_new_root = cfg.create_new_root; E.sync_moves = cfg.sync_moves; E.use_dirichlet = cfg.use_dirichlet;
         int npt = cfg.nodes_per_tree;
+        if (npt <= 0 && gumbel) npt = 2 * (cfg.run_iterations + cfg.gumbel_m) + 3 * G::A + 64;   // fresh tree every move
         if (npt <= 0) {   // a tree lives for the whole game and gains <= 1 record per simulation of its own moves
             const int own_moves = (cfg.max_actions + 1) / 2 + 1;
             int its = cfg.run_iterations < 3 * G::A ? 3 * G::A : cfg.run_iterations;
@@ -164,13 +176,14 @@ template <class G> struct EngineT : gaz_engine {
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
         E.key0 = (uint32_t)cfg.seed; E.key1 = (uint32_t)(cfg.seed >> 32); E.slot_offset = cfg.slot_offset;
-        const size_t arena_bytes = (size_t)n * 2 * (size_t)npt * NodeLayout<G>::SIZE;
+        const size_t arena_bytes = (size_t)n * 2 * (size_t)npt * (size_t)E.node_bytes;
         void* a = nullptr;
         HIP_OK(hipMalloc(&a, arena_bytes));               // not zeroed: every record is written before it is read
         allocs.push_back(a); E.arena = (uint8_t*)a;
         if (dalloc(&E.trees, (size_t)n * 2)) return 1;
         if (dalloc(&E.games, (size_t)n)) return 1;
         if (dalloc(&E.paths, (size_t)n * PATH_CAP)) return 1;
+        if (gumbel) { GumbelState<G>* gp = nullptr; if (dalloc(&gp, (size_t)n)) return 1; E.gstate = gp; }
         if (dalloc(&E.recs, (size_t)n * RL::SIZE)) return 1;
         if (dalloc(&E.ring, (size_t)(cfg.ring_capacity > 0 ? cfg.ring_capacity : 1) * RL::SIZE)) return 1;
         if (dalloc(&E.ring_head, 4)) return 1;
@@ -223,10 +236,15 @@ template <class G> struct EngineT : gaz_engine {
 
     hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
 
+    void launch_wave() {
+        if (cfg.search == GAZ_SEARCH_GUMBEL) GAZ_LAUNCH(k_wave_gumbel<G>, E.n_games, WAVE, stream, E);
+        else GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+    }
+
     int one_wave(bool with_eval) {
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
-        GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+        launch_wave();
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
         if (timing) hipEventRecord(e2, stream);
@@ -247,7 +265,9 @@ template <class G> struct EngineT : gaz_engine {
         if (!eval) return fail("run_move needs a built-in evaluator (use wave_begin/wave_end with GAZ_EVAL_EXTERNAL)");
         if (!eval->ready()) return fail("run_move: evaluator weights not loaded (gaz_engine_load_weights)");
         // a move needs at most iter_limit + 2 evaluations (both roots); poll the device every 16 waves
-        const int max_waves = (E.run_iterations < 3 * G::A ? 3 * G::A : E.run_iterations) + 8;
+        // PUCT: a move needs at most iter_limit + 2 evaluations; Gumbel can overshoot its budget (vpc >= 1 per survivor)
+        const int max_waves = cfg.search == GAZ_SEARCH_GUMBEL ? 4 * (E.run_iterations + 3 * G::A) + 64
+                                                             : (E.run_iterations < 3 * G::A ? 3 * G::A : E.run_iterations) + 8;
         int32_t c[8];
         for (int w = 0; w < max_waves + 16; w += 16) {
             for (int i = 0; i < 16; ++i) one_wave(true);
@@ -283,7 +303,7 @@ template <class G> struct EngineT : gaz_engine {
         GAZ_LAUNCH(k_release<G>, E.n_games, WAVE, stream, E, moves ? (const int32_t*)dMoves : (const int32_t*)nullptr);
         HIP_OK(hipGetLastError());
         // run the APPLY phase (do_action, win check, prune) up to the next evaluation request
-        GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+        launch_wave();
         if (eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, false);
         HIP_OK(hipGetLastError());
         return check_device_error();

@@ -1,0 +1,473 @@
+// gumbel_core.hpp — Gumbel AlphaZero search (sequential halving at the root, completed-Q deterministic selection
+// below it) and the use_gumbel branch of the self-play loop, one wavefront per game.
+//
+// Reference path replaced (file:line under /root/reference):
+//   stablemax / softmax / q_transform / rescale_q / sigma / compute_v_mix / compute_pi   MCTS_Gumbel.py:75-148   -> compute_pi()
+//   MCTS_Gumbel.sequential_halving                                                    MCTS_Gumbel.py:212-224  -> g_halving()
+//   MCTS_Gumbel.deterministic_selection / select                                      MCTS_Gumbel.py:226-260  -> g_select()
+//   MCTS_Gumbel.get_terminal_actions_fn (unsorted)                                    MCTS_Gumbel.py:281-318  -> terminal_probe_unsorted()
+//   MCTS_Gumbel.create_expand_root / _expand / _expand_with_terminal_actions          MCTS_Gumbel.py:320-528  -> g_root_pre/post, g_expand_pre/post
+//   MCTS_Gumbel._back_propagate                                                       MCTS_Gumbel.py:530-546  -> backup() (shared with PUCT)
+//   MCTS_Gumbel.run                                                                   MCTS_Gumbel.py:562-679  -> phases of g_game_step
+//   Self_Play.create_MCTS_Gumbel / play (use_gumbel)                                  Self_Play.py:58-69,108-153 (fresh tree every move)
+//
+// Numerics follow numpy-without-Numba (how the fixtures were recorded): float32 statistics, float64 softmax with the
+// det:: exp, numpy's pairwise summation order, stable ascending argsort.  A node keeps its children in LEGAL-ACTION
+// order (no prior sort), with raw logits in P[] and the evaluator value of each expanded child in RAW[].
+#pragma once
+#include "puct_core.hpp"
+
+namespace gaz {
+
+template <class G> struct GumbelState {          // per game, lives across launches of one MCTS_Gumbel.run
+    int32_t m_eff, phase, n_top, cand, stage, sims_left, vpc, cur_iter, pend_counts;
+    float top_logits[G::APAD];
+    float top_mean[G::APAD];
+    uint8_t top_ids[G::APAD];
+};
+
+template <class G> GAZ_DEV float* node_raw(const NodeRef<G>& nd) {
+    return reinterpret_cast<float*>(nd.p + NodeLayout<G>::SIZE);      // RAW[APAD] is appended after the PUCT record
+}
+template <class G> constexpr int gumbel_node_bytes() { return NodeLayout<G>::SIZE + 4 * G::APAD; }
+
+constexpr float F32_EPS = 1.1920928955078125e-07f;
+
+// terminal moves in order of appearance (MCTS_Gumbel.py:301-318)
+template <class G> GAZ_DEV int terminal_probe_unsorted(const int8_t* board, const uint8_t* legal, int n_legal, int player,
+                                                       uint8_t* tact, uint8_t* twin, bool& any_win) {
+    const int empties = G::DRAWS ? count_empty<G>(board) : 0;
+    int nt = 0; uint64_t anyw = 0;
+    for (int base = 0; base < n_legal; base += WAVE) {
+        int i = base + lane_id();
+        bool win = false, hit = false;
+        if (i < n_legal) {
+            win = wins_after<G>(board, landing_cell<G>(board, legal[i]), player);
+            hit = win || (G::DRAWS && empties == 1);
+        }
+        uint64_t m = ballot(hit);
+        anyw |= ballot(win);
+        if (hit) { int pos = nt + popcll(m & ((1ull << lane_id()) - 1ull)); tact[pos] = legal[i]; twin[pos] = win ? 1 : 0; }
+        nt += popcll(m);
+    }
+    any_win = anyw != 0;
+    wave_sync();
+    return nt;
+}
+
+// softmax in float64 over S.gam[0..n): x <- exp(x - max) / np.sum(...)   (MCTS_Gumbel.py:82-88)
+template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
+    double mx = S.gam[0];
+    for (int i = 1; i < n; ++i) { double v = S.gam[i]; if (v > mx) mx = v; }       // uniform
+    wave_sync();
+    const double c = -mx;
+    for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = det::dexp(S.gam[i] + c);
+    wave_sync();
+    const double s = det::np_pairwise_sum<double>(S.gam, n);
+    wave_sync();
+    for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = S.gam[i] / s;
+    wave_sync();
+}
+
+// compute_pi(use_softmax=True) for node nd (MCTS_Gumbel.py:126-141 with :113-124, :99-103, :106-110).  Result f32 in S.pri.
+template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, int n, Scratch<G>& S, uint32_t& N_b_out,
+                                           uint64_t& sumv_out) {
+    const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P(); const float* RAW = node_raw<G>(nd);
+    uint32_t nb = 0; uint64_t sumv = 0;
+    for (int i = 0; i < n; ++i) { uint32_t v = N[i]; if (v > nb) nb = v; sumv += v; }              // uniform
+    for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)L[i];
+    wave_sync();
+    softmax_inplace<G>(S, n);
+    // probs (f32) in S.pri; q in S.aux
+    for (int i = lane_id(); i < n; i += WAVE) {
+        S.pri[i] = (float)S.gam[i];
+        const float mean = N[i] > 0 ? (float)((double)W[i] / (double)N[i]) : -1.0f;               // mean_values, q_transform
+        S.aux[i] = (mean - (-1.0f)) / 2.0f;
+    }
+    wave_sync();
+    for (int i = lane_id(); i < n; i += WAVE) S.spri[i] = N[i] > 0 ? S.pri[i] : 0.0f;
+    wave_sync();
+    const float sum_probs = det::np_pairwise_sum<float>(S.spri, n);
+    wave_sync();
+    for (int i = lane_id(); i < n; i += WAVE) S.spri[i] = N[i] > 0 ? (S.pri[i] * S.aux[i]) / sum_probs : 0.0f;
+    wave_sync();
+    const float weighted_q = det::np_pairwise_sum<float>(S.spri, n);
+    wave_sync();
+    const double wq = (double)weighted_q * (double)sumv;
+    for (int i = lane_id(); i < n; i += WAVE) {
+        const float vmix = (float)(((double)RAW[i] + wq) / (double)(sumv + 1));
+        S.spri[i] = N[i] > 0 ? S.aux[i] : vmix;                                                   // completed_q
+    }
+    wave_sync();
+    float mn = S.spri[0], mx = S.spri[0];
+    for (int i = 1; i < n; ++i) { float v = S.spri[i]; if (v < mn) mn = v; if (v > mx) mx = v; }   // uniform
+    const float den = (mx - mn) > F32_EPS ? (mx - mn) : F32_EPS;
+    const double sg = (E.c_visit + (double)nb) * E.c_scale;
+    wave_sync();
+    for (int i = lane_id(); i < n; i += WAVE) { const float r = (S.spri[i] - mn) / den; S.gam[i] = (double)L[i] + sg * (double)r; }
+    wave_sync();
+    softmax_inplace<G>(S, n);
+    for (int i = lane_id(); i < n; i += WAVE) S.pri[i] = (float)S.gam[i];
+    wave_sync();
+    N_b_out = nb; sumv_out = sumv;
+}
+
+// deterministic_selection: argmax(pi - visits / (1 + sum(visits))) in float64, first maximum (MCTS_Gumbel.py:243)
+template <class G> GAZ_DEV int g_det_select(const DevParams<G>& E, const NodeRef<G>& nd, int n, Scratch<G>& S) {
+    uint32_t nb; uint64_t sumv;
+    compute_pi<G>(E, nd, n, S, nb, sumv);
+    double best = 0.0; int bi = 0x7fffffff;
+    for (int i = lane_id(); i < n; i += WAVE) {
+        double sc = (double)S.pri[i] - (double)nd.N()[i] / (double)(1 + sumv);
+        if (bi == 0x7fffffff || sc > best) { best = sc; bi = i; }
+    }
+    wave_argmax(best, bi);
+    wave_sync();
+    return uni(bi);
+}
+
+// sequential_halving + the bookkeeping around it (MCTS_Gumbel.py:603-623).  Returns false when one candidate is left.
+template <class G> GAZ_DEV bool g_halving(const DevParams<G>& E, GumbelState<G>& gu, const NodeRef<G>& r, int n_root, Scratch<G>& S) {
+    const int m = gu.m_eff, phase = gu.phase, n_top = gu.n_top;
+    double halved = (double)m / (double)(1 << (phase < 30 ? phase : 30)); if (halved < 1.0) halved = 1.0;
+    uint32_t nb = 0; for (int i = 0; i < n_root; ++i) { uint32_t v = r.N()[i]; if (v > nb) nb = v; }
+    const double sg = (E.c_visit + (double)nb) * E.c_scale;
+    for (int i = lane_id(); i < n_top; i += WAVE) {
+        double sc = (double)gu.top_logits[i];
+        if (phase > 0) { const float qh = (gu.top_mean[i] - (-1.0f)) / 2.0f; sc = sc + sg * (double)qh; }
+        S.gam[i] = sc;
+    }
+    wave_sync();
+    int take = phase == 0 ? m : (int)halved; if (take > n_top) take = n_top;
+    for (int i = lane_id(); i < n_top; i += WAVE) {          // stable ascending rank; keep the `take` largest in ascending order
+        const double v = S.gam[i]; int rank = 0;
+        for (int j = 0; j < n_top; ++j) { const double o = S.gam[j]; rank += (o < v) || (o == v && j < i); }
+        const int pos = rank - (n_top - take);
+        if (pos >= 0) { S.spri[pos] = gu.top_logits[i]; S.sact[pos] = gu.top_ids[i]; }
+    }
+    wave_sync();
+    for (int i = lane_id(); i < take; i += WAVE) { gu.top_logits[i] = S.spri[i]; gu.top_ids[i] = S.sact[i]; }
+    double lg2;                                              // np.log2(m): exact for powers of two
+    if ((m & (m - 1)) == 0) { lg2 = 0.0; for (int mm = m; mm > 1; mm >>= 1) lg2 += 1.0; }
+    else lg2 = det::dlog((double)m) / 0.6931471805599453;
+    int vpc = m > 1 ? (int)((double)E.run_iterations / (lg2 * halved)) : E.run_iterations; if (vpc < 1) vpc = 1;
+    if (take == 2 || take == 3) { vpc = (E.run_iterations - gu.cur_iter) / take; if (vpc < 1) vpc = 1; }
+    wave_sync();
+    if (lane_id() == 0) { gu.n_top = take; gu.vpc = vpc; gu.cand = 0; gu.stage = 0; }
+    wave_sync();
+    return take > 1;
+}
+
+// create_expand_root, first half
+template <class G> GAZ_DEV bool g_root_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S) {
+    if (lane_id() == 0) { ts.n_nodes = 0; ts.root = -1; ts.root_visits = 0; }
+    wave_sync();
+    copy_board<G>(S.board, gs.board);
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    bool any_win;
+    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win);
+    uint8_t h3[3];
+    for (int i = 0; i < 3; ++i) h3[i] = (gs.n_hist - 1 - i >= 0) ? gs.hist[gs.n_hist - 1 - i] : 0;
+    const int idx = alloc_node(E, ts);
+    if (idx < 0) return false;
+    NodeRef<G> nd = node_at(E, g, 0, idx);
+    if (lane_id() == 0) {
+        NodeHdr h; memset(&h, 0, sizeof(h));
+        h.parent = -1; h.player = (int8_t)(-gs.next_player); h.n_hist = (uint16_t)gs.n_hist;
+        h.hist3[0] = h3[0]; h.hist3[1] = h3[1]; h.hist3[2] = h3[2]; h.action = h3[0];
+        if (nt > 0) { h.n_actions = (uint8_t)nt; h.n_children = (uint8_t)nt; h.flags = NF_TERMINAL_PARENT; }
+        *nd.hdr() = h; ts.root = idx;
+    }
+    copy_board<G>(nd.board(), S.board);
+    if (nt > 0) {                                                              // MCTS_Gumbel.py:339-370
+        for (int i = lane_id(); i < nt; i += WAVE) {
+            const float mask = S.twin[i] ? 1.0f : 0.0f;
+            nd.N()[i] = 1u; nd.W()[i] = any_win ? 1.0f : 0.0f; node_raw<G>(nd)[i] = mask;
+            nd.P()[i] = any_win ? mask / (float)nt : 1.0f / (float)nt;
+            nd.child()[i] = S.twin[i] ? CHILD_LEAF_WIN : CHILD_LEAF_DRAW; nd.act()[i] = S.tact[i];
+        }
+        if (lane_id() == 0) ts.root_visits = (uint64_t)nt;
+        wave_sync();
+        return false;
+    }
+    encode_input<G>(S.board, -gs.next_player, h3, gs.n_hist, E.nn_in + (size_t)g * (G::HW * G::C));
+    wave_sync();
+    return true;
+}
+
+// children of a freshly evaluated node: raw logits of the legal actions in legal order (normalize=False), all unexpanded
+template <class G> GAZ_DEV void g_write_children(const DevParams<G>& E, int g, const NodeRef<G>& nd, Scratch<G>& S) {
+    copy_board<G>(S.board, nd.board());
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    const float* policy = E.nn_policy + (size_t)g * G::A;
+    for (int i = lane_id(); i < n_legal; i += WAVE) {
+        nd.N()[i] = 0u; nd.W()[i] = 0.0f; node_raw<G>(nd)[i] = 0.0f; nd.P()[i] = policy[S.legal[i]];
+        nd.child()[i] = CHILD_NONE; nd.act()[i] = S.legal[i];
+    }
+    if (lane_id() == 0) { nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0; }
+    wave_sync();
+}
+
+// _expand of child `index` of `node`; path[0..depth) leads to node.  true = evaluation pending
+template <class G> GAZ_DEV bool g_expand_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S,
+                                             int node, int index, int depth) {
+    NodeRef<G> pn = node_at(E, g, 0, node);
+    const NodeHdr ph = *pn.hdr();
+    const int action = uni((int)pn.act()[index]);
+    const int mover = -(int)uni((int)ph.player);
+    copy_board<G>(S.board, pn.board());
+    wave_sync();
+    const int cell = landing_cell<G>(S.board, action);
+    wave_sync();
+    if (lane_id() == 0) S.board[cell] = (int8_t)mover;
+    wave_sync();
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    bool any_win;
+    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win);
+    const int idx = alloc_node(E, ts);
+    if (idx < 0) return false;
+    NodeRef<G> nd = node_at(E, g, 0, idx);
+    if (lane_id() == 0) {
+        NodeHdr h; memset(&h, 0, sizeof(h));
+        h.parent = node; h.slot = (int16_t)index; h.player = (int8_t)mover; h.n_hist = (uint16_t)(ph.n_hist + 1);
+        h.hist3[0] = (uint8_t)action; h.hist3[1] = ph.hist3[0]; h.hist3[2] = ph.hist3[1]; h.action = (uint8_t)action;
+        if (nt > 0) { h.n_actions = (uint8_t)nt; h.n_children = (uint8_t)nt; h.flags = NF_TERMINAL_PARENT; }
+        *nd.hdr() = h;
+    }
+    S.path[depth].node = node; S.path[depth].slot = index;
+    copy_board<G>(nd.board(), S.board);
+    wave_sync();
+    if (nt > 0) {                                                              // MCTS_Gumbel.py:391-453: visits / values stay 0
+        for (int i = lane_id(); i < nt; i += WAVE) {
+            const float mask = S.twin[i] ? 1.0f : 0.0f;
+            nd.N()[i] = 0u; nd.W()[i] = 0.0f; node_raw<G>(nd)[i] = mask;
+            nd.P()[i] = any_win ? mask / (float)nt : 1.0f / (float)nt;
+            nd.child()[i] = S.twin[i] ? CHILD_LEAF_WIN : CHILD_LEAF_DRAW; nd.act()[i] = S.tact[i];
+        }
+        if (lane_id() == 0) pn.child()[index] = idx;
+        wave_sync();
+        backup<G>(E, g, 0, ts, S.path, depth + 1, any_win ? -(float)nt : 0.0f, (uint32_t)nt);
+        return false;
+    }
+    uint8_t h3[3] = {(uint8_t)action, ph.hist3[0], ph.hist3[1]};
+    encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
+    PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    for (int d = lane_id(); d <= depth; d += WAVE) gp[d] = S.path[d];
+    if (lane_id() == 0) {
+        gs.pend_kind = PEND_EXPAND; gs.pend_tree = 0; gs.pend_parent = node; gs.pend_slot = index; gs.pend_node = idx;
+        gs.pend_depth = depth + 1;
+    }
+    wave_sync();
+    return true;
+}
+
+template <class G> GAZ_DEV void g_expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S) {
+    const int node = gs.pend_parent, index = gs.pend_slot, idx = gs.pend_node, depth = gs.pend_depth;
+    NodeRef<G> nd = node_at(E, g, 0, idx);
+    g_write_children<G>(E, g, nd, S);
+    NodeRef<G> pn = node_at(E, g, 0, node);
+    const float value = E.nn_value[g];
+    if (lane_id() == 0) { pn.child()[index] = idx; node_raw<G>(pn)[index] = value; }       // MCTS_Gumbel.py:516-517
+    const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    wave_sync();
+    backup<G>(E, g, 0, ts, S.path, depth, -value, 1u);
+}
+
+// end of MCTS_Gumbel.run (MCTS_Gumbel.py:653-679) + Self_Play bookkeeping
+template <class G> GAZ_DEV void g_move_end(const DevParams<G>& E, int g, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts, Scratch<G>& S) {
+    using RL = RecLayout<G>;
+    NodeRef<G> r = node_at(E, g, 0, ts.root);
+    const int n = uni((int)r.hdr()->n_actions);
+    uint32_t nb; uint64_t sumv;
+    compute_pi<G>(E, r, n, S, nb, sumv);                                        // pi in S.pri
+    uint8_t* rec = rec_of(E, g);
+    const int ply = gs.n_hist;
+    float* pol = reinterpret_cast<float*>(rec + RL::OFF_POL) + (size_t)ply * G::A;
+    uint32_t* rN = reinterpret_cast<uint32_t*>(rec + RL::OFF_N) + (size_t)ply * G::A;
+    float* rW = reinterpret_cast<float*>(rec + RL::OFF_W) + (size_t)ply * G::A;
+    float* rP = reinterpret_cast<float*>(rec + RL::OFF_P) + (size_t)ply * G::A;
+    for (int a = lane_id(); a < G::A; a += WAVE) { pol[a] = 0.0f; rN[a] = 0u; rW[a] = 0.0f; rP[a] = 0.0f; }
+    wave_sync();
+    for (int i = lane_id(); i < n; i += WAVE) {
+        const int a = r.act()[i];
+        pol[a] = S.pri[i]; rN[a] = r.N()[i]; rW[a] = r.W()[i]; rP[a] = r.P()[i];
+    }
+    const int top = (gu.n_top > 0) ? (int)gu.top_ids[0] : 0;
+    if (lane_id() == 0) {
+        gs.chosen = r.act()[top];                                               // children[top_node_ids[0]] (MCTS_Gumbel.py:679)
+        const uint32_t nv = r.N()[top];
+        const float mean = nv > 0 ? (float)((double)r.W()[top] / (double)nv) : S.pri[top];   // unvisited winrate := pi (:666-667)
+        reinterpret_cast<float*>(rec + RL::OFF_Q)[ply] = mean;
+        reinterpret_cast<uint32_t*>(rec + RL::OFF_RV)[ply] = (uint32_t)ts.root_visits;
+        reinterpret_cast<uint32_t*>(rec + RL::OFF_EV)[ply] = gs.move_evals;
+    }
+    wave_sync();
+}
+
+template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S) {
+    using RL = RecLayout<G>;
+    GameState<G>& gs = E.games[g];
+    GumbelState<G>& gu = reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
+    TreeState& ts = E.trees[(size_t)g * 2];
+
+    if (uni(gs.pend_kind) == PEND_ROOT) {
+        g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S);
+        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo = 0; gs.n_evals += 1; }
+        wave_sync();
+    } else if (uni(gs.pend_kind) == PEND_EXPAND) {
+        g_expand_post<G>(E, g, gs, ts, S);
+        if (lane_id() == 0) {
+            gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1;
+            if (gu.pend_counts) { gu.sims_left -= 1; gu.cur_iter += 1; gs.n_sims += 1; }
+        }
+        wave_sync();
+    }
+
+    int tree_only = 0;
+    for (int guard = 0; guard < 100000; ++guard) {
+        const int phase = uni(gs.phase);
+        if (phase == PH_NEW_GAME) {
+            for (int c = lane_id(); c < G::BPAD; c += WAVE) gs.board[c] = 0;
+            if (lane_id() == 0) {
+                gs.n_hist = 0; gs.next_player = -1; gs.roots_todo = 1; gs.phase = PH_ROOT; gs.winner = RUNNING; gs.host_move = -1;
+                gs.move_evals = 0; ts.root = -1; ts.event = 0; ts.n_nodes = 0; ts.root_visits = 0;
+            }
+            wave_sync();
+        } else if (phase == PH_ROOT) {
+            if (uni(gs.roots_todo) == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
+            if (lane_id() == 0) gs.move_evals = 0;
+            if (g_root_pre<G>(E, g, gs, ts, S)) {
+                if (lane_id() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = 0; }
+                wave_sync();
+                return;
+            }
+            if (lane_id() == 0) gs.roots_todo = 0;
+            wave_sync();
+            if (uni(*E.error)) return;
+        } else if (phase == PH_MOVE_BEGIN) {                                   // head of MCTS_Gumbel.run (:570-599)
+            copy_board<G>(S.board, gs.board);
+            wave_sync();
+            const int len_legal = build_legal<G>(S.board, S.legal);
+            NodeRef<G> r = node_at(E, g, 0, ts.root);
+            const int n = uni((int)r.hdr()->n_actions);
+            det::Event e = make_event(E, g, gs, ts, 0, det::P_GUMBEL);
+            for (int i = lane_id(); i < n; i += WAVE) {
+                gu.top_logits[i] = (float)((double)r.P()[i] + det::gumbel(e, (uint32_t)i));     // use_gumbel_noise=True (Self_Play.py:64)
+                gu.top_ids[i] = (uint8_t)i; gu.top_mean[i] = r.W()[i];
+            }
+            if (lane_id() == 0) {
+                ts.event += 1;
+                gu.m_eff = E.gumbel_m < len_legal ? E.gumbel_m : len_legal; gu.phase = 0; gu.n_top = n; gu.cur_iter = 0;
+                gu.cand = 0; gu.stage = 0; gu.sims_left = 0; gu.pend_counts = 0;
+            }
+            wave_sync();
+            bool go = len_legal > 1;
+            if (go) go = g_halving<G>(E, gu, r, n, S);
+            if (lane_id() == 0) gs.phase = go ? PH_SIMS : PH_MOVE_END;
+            wave_sync();
+        } else if (phase == PH_SIMS) {                                         // MCTS_Gumbel.py:625-648
+            NodeRef<G> r = node_at(E, g, 0, ts.root);
+            const int n_root = uni((int)r.hdr()->n_actions);
+            if (uni(gu.cand) >= uni(gu.n_top)) {                               // phase finished: q-hat of the survivors, halve again
+                for (int c = lane_id(); c < gu.n_top; c += WAVE) {
+                    const int id = gu.top_ids[c];
+                    gu.top_mean[c] = (float)((double)r.W()[id] / (double)r.N()[id]);
+                }
+                if (lane_id() == 0) gu.phase += 1;
+                wave_sync();
+                const bool go = g_halving<G>(E, gu, r, n_root, S);
+                if (!go) { if (lane_id() == 0) gs.phase = PH_MOVE_END; wave_sync(); }
+                continue;
+            }
+            const int id = uni((int)gu.top_ids[uni(gu.cand)]);
+            if (uni(gu.stage) == 0) {                                          // expand the root child first (not an iteration)
+                if (lane_id() == 0) { gu.stage = 1; gu.sims_left = gu.vpc; gu.pend_counts = 0; }
+                wave_sync();
+                if (uni(r.child()[id]) == CHILD_NONE) {
+                    if (g_expand_pre<G>(E, g, gs, ts, S, ts.root, id, 0)) return;
+                    if (uni(*E.error)) return;
+                }
+                continue;
+            }
+            if (uni(gu.sims_left) <= 0) { if (lane_id() == 0) { gu.cand += 1; gu.stage = 0; } wave_sync(); continue; }
+            if (tree_only >= E.max_tree_sims) return;
+            tree_only++;
+            // one simulation below root child `id`
+            int node = ts.root, depth = 0, slot = id;
+            bool done = false, pending = false;
+            for (;;) {
+                NodeRef<G> nd = node_at(E, g, 0, node);
+                const int c = uni(nd.child()[slot]);
+                if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return; }
+                if (c == CHILD_NONE) {                                         // expand (node, slot)
+                    if (lane_id() == 0) gu.pend_counts = 1;
+                    wave_sync();
+                    pending = g_expand_pre<G>(E, g, gs, ts, S, node, slot, depth);
+                    done = !pending;
+                    break;
+                }
+                S.path[depth].node = node; S.path[depth].slot = slot; depth++;
+                if (c == CHILD_LEAF_WIN || c == CHILD_LEAF_DRAW) {             // terminal child: value 1 / 0 (:635-637)
+                    wave_sync();
+                    backup<G>(E, g, 0, ts, S.path, depth, c == CHILD_LEAF_WIN ? 1.0f : 0.0f, 1u);
+                    done = true;
+                    break;
+                }
+                node = c;
+                NodeRef<G> cn = node_at(E, g, 0, node);
+                slot = g_det_select<G>(E, cn, uni((int)cn.hdr()->n_actions), S);
+            }
+            if (pending) return;
+            if (uni(*E.error)) return;
+            if (done && lane_id() == 0) { gu.sims_left -= 1; gu.cur_iter += 1; gs.n_sims += 1; }
+            wave_sync();
+        } else if (phase == PH_MOVE_END) {
+            g_move_end<G>(E, g, gs, gu, ts, S);
+            if (lane_id() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
+            wave_sync();
+            if (E.sync_moves) return;
+        } else if (phase == PH_APPLY) {                                        // Self_Play.py:142-157, new tree every move (:151-153)
+            const int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            const int mover = uni(gs.next_player);
+            copy_board<G>(S.board, gs.board);
+            wave_sync();
+            const int cell = landing_cell<G>(S.board, action);
+            const bool win = wins_after<G>(S.board, cell, mover);
+            const int empties = G::DRAWS ? count_empty<G>(S.board) : 2;
+            uint8_t* rec = rec_of(E, g);
+            const int ply = gs.n_hist;
+            int winner = win ? mover : ((G::DRAWS && empties == 1) ? 0 : RUNNING);
+            wave_sync();
+            if (lane_id() == 0) {
+                gs.board[cell] = (int8_t)mover; gs.hist[ply] = (uint8_t)action; rec[RL::OFF_ACT + ply] = (uint8_t)action;
+                gs.n_hist = ply + 1; gs.next_player = -mover; gs.host_move = -1; gs.n_plies += 1;
+            }
+            wave_sync();
+            bool ended = winner != RUNNING;
+            if (ply + 1 == E.max_actions) { winner = 0; ended = true; }
+            if (!ended && lane_id() == 0) { gs.roots_todo = 1; gs.phase = PH_ROOT; }
+            if (ended && lane_id() == 0) {
+                gs.winner = winner;
+                int32_t* hdr = reinterpret_cast<int32_t*>(rec);
+                hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)(E.slot_offset + (uint32_t)g); hdr[3] = (int32_t)gs.game_seq;
+                atomic_max(&E.stats[0], (unsigned long long)(ply + 1));
+                atomic_add(&E.stats[1], (unsigned long long)(ply + 1));
+                atomic_add(&E.stats[2], 1ull);
+                atomic_add(&E.stats[winner + 4], 1ull);
+                gs.phase = PH_RING_WAIT;
+            }
+            wave_sync();
+        } else if (phase == PH_RING_WAIT) {
+            if (!ring_push<G>(E, g, gs)) return;
+            if (E.sync_moves) return;
+        } else {
+            return;
+        }
+    }
+    set_error(E.error, ERR_LOOP_GUARD);
+}
+
+}  // namespace gaz

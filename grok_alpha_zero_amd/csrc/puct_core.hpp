@@ -35,12 +35,15 @@ template <class G> struct DevParams {
     int32_t n_games, run_iterations, max_actions, explore_first, explore_second;
     int32_t create_new_root, sync_moves, nodes_per_tree, ring_cap, use_dirichlet, max_tree_sims;
     double c_init, c_base, alpha, eps;
+    double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
+    int32_t gumbel_m, node_bytes;
     float one_minus_eps;
     uint32_t key0, key1, slot_offset;
     // state in HBM
     uint8_t* arena;            // [n_games][2][nodes_per_tree][NodeLayout::SIZE]
     TreeState* trees;          // [n_games][2]
     GameState<G>* games;       // [n_games]
+    void* gstate;              // [n_games] GumbelState (Gumbel search only)
     PathEnt* paths;            // [n_games][PATH_CAP] path of the pending expansion (root -> leaf edge list)
     uint8_t* recs;             // [n_games][RecLayout::SIZE] game in progress
     uint8_t* ring;             // [ring_cap][RecLayout::SIZE] finished games
@@ -63,6 +66,7 @@ template <class G> struct Scratch {   // per-wave LDS
     uint8_t sact[G::APAD];     // sorted actions
     float pri[G::APAD];
     float spri[G::APAD];
+    float aux[G::APAD];
     double gam[G::APAD];
     PathEnt path[PATH_CAP];
 };
@@ -76,7 +80,7 @@ template <class T> GAZ_DEV T uni(T v) {
 }
 
 template <class G> GAZ_DEV NodeRef<G> node_at(const DevParams<G>& E, int g, int t, int idx) {
-    size_t off = (((size_t)g * 2 + t) * (size_t)E.nodes_per_tree + (size_t)idx) * (size_t)NodeLayout<G>::SIZE;
+    size_t off = (((size_t)g * 2 + t) * (size_t)E.nodes_per_tree + (size_t)idx) * (size_t)E.node_bytes;
     return NodeRef<G>{E.arena + off};
 }
 
@@ -534,6 +538,31 @@ template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState
     wave_sync();
 }
 
+// Finished game -> host ring (or dropped when no ring is configured), then restart / halt the slot.  false = ring full.
+template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameState<G>& gs) {
+    using RL = RecLayout<G>;
+    if (E.ring_cap > 0) {
+        int slot = -1;
+        if (lane_id() == 0) {                                          // single consumer (host, between launches) / many producers
+            uint32_t prod = atomic_add(&E.ring_head[0], 1u);
+            if (prod - E.ring_head[1] < (uint32_t)E.ring_cap) slot = (int)(prod % (uint32_t)E.ring_cap);
+            else atomic_add(&E.ring_head[0], (uint32_t)-1);
+        }
+        slot = shfl(slot, 0);
+        if (slot < 0) return false;                                    // ring full: retry next launch
+        const uint4* src = reinterpret_cast<const uint4*>(rec_of(E, g));
+        uint4* dst = reinterpret_cast<uint4*>(E.ring + (size_t)slot * RL::SIZE);
+        for (int i = lane_id(); i < RL::SIZE / 16; i += WAVE) dst[i] = src[i];
+        wave_sync();
+    }
+    if (lane_id() == 0) {
+        if (E.sync_moves) gs.phase = PH_HALT;
+        else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
+    }
+    wave_sync();
+    return true;
+}
+
 // One launch of the wave kernel for game g: consume the pending evaluation, then run until the next one.
 template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S) {
     using RL = RecLayout<G>;
@@ -708,33 +737,7 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
             }
             wave_sync();
         } else if (phase == PH_RING_WAIT) {                            // hand the finished game to the host ring
-            int slot = -1;
-            if (E.ring_cap <= 0) {                                     // no record ring configured: drop the record
-                if (lane_id() == 0) {
-                    if (E.sync_moves) gs.phase = PH_HALT;
-                    else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
-                }
-                wave_sync();
-                if (E.sync_moves) return;
-                continue;
-            }
-            if (lane_id() == 0) {
-                // single consumer (host, between launches) / many producers
-                uint32_t prod = atomic_add(&E.ring_head[0], 1u);
-                if (prod - E.ring_head[1] < (uint32_t)E.ring_cap) slot = (int)(prod % (uint32_t)E.ring_cap);
-                else atomic_add(&E.ring_head[0], (uint32_t)-1);
-            }
-            slot = shfl(slot, 0);
-            if (slot < 0) return;                                      // ring full: retry next launch
-            const uint4* src = reinterpret_cast<const uint4*>(rec_of(E, g));
-            uint4* dst = reinterpret_cast<uint4*>(E.ring + (size_t)slot * RL::SIZE);
-            for (int i = lane_id(); i < RL::SIZE / 16; i += WAVE) dst[i] = src[i];
-            wave_sync();
-            if (lane_id() == 0) {
-                if (E.sync_moves) gs.phase = PH_HALT;
-                else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
-            }
-            wave_sync();
+            if (!ring_push<G>(E, g, gs)) return;
             if (E.sync_moves) return;
         } else {                                                       // PH_WAIT_HOST, PH_HALT
             return;

@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-from .engine import EVAL_HASH, EVAL_RESNET, SelfPlayEngine
+from .engine import EVAL_HASH, EVAL_RESNET, SEARCH_GUMBEL, SEARCH_PUCT, SelfPlayEngine
 
 
 class ReplayStore:
@@ -119,17 +119,21 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     games_left = int(train_config["games_per_generation"] - store.game_stats()[2])
     if games_left <= 0:
         return 0
-    if train_config.get("use_gumbel"):
-        raise NotImplementedError("the Gumbel search path is not in this library version")
     generation = int(str(folder_path).rstrip("/").split("/")[-1])
     name = getattr(game_class, "ENGINE_NAME", game_class.__name__)
     use_net = generation > 0 and weights is not None
     G = min(n_games, games_left)
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")                 # np.random.seed() from OS entropy (Self_Play.py:221)
-    eng = SelfPlayEngine(name, G, int(train_config["MCTS_iteration_limit"] * 1.5), train_config["max_actions"],
-                         train_config["num_explore_actions_first"], train_config["num_explore_actions_second"],
-                         train_config["c_puct_init"], train_config["dirichlet_alpha"], seed,
+    gumbel = bool(train_config.get("use_gumbel"))
+    # PUCT runs int(1.5 * limit) iterations per move (Self_Play.py:99), Gumbel runs `limit` (Self_Play.py:110-112)
+    iters = int(train_config["MCTS_iteration_limit"]) if gumbel else int(train_config["MCTS_iteration_limit"] * 1.5)
+    eng = SelfPlayEngine(name, G, iters, train_config["max_actions"],
+                         train_config.get("num_explore_actions_first", 0), train_config.get("num_explore_actions_second", 0),
+                         train_config.get("c_puct_init", 0.0), train_config.get("dirichlet_alpha", 0.0), seed,
+                         search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=train_config.get("m", 0),
+                         c_visit=train_config.get("c_visit", 50.0), c_scale=train_config.get("c_scale", 1.0),
+                         policy_is_logits=gumbel,
                          create_new_root=train_config.get("create_new_root", False), slot_offset=slot_offset, device=device,
                          evaluator=EVAL_RESNET if use_net else EVAL_HASH, hash_salt=hash_salt,
                          net_blocks=build_config.get("num_resnet_layers", 0) if use_net else 0,

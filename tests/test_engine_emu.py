@@ -112,3 +112,28 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), n
+
+
+GUMBEL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_gumbel_*.npz")))
+
+
+def play_gumbel_fixture(fx, lib_path):
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, SEARCH_GUMBEL
+    eng = SelfPlayEngine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), 0, 0, 0.0, 0.0, int(fx["seed"]),
+                         slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8, search=SEARCH_GUMBEL,
+                         gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]), lib_path=lib_path)
+    recs = []
+    for _ in range(20000):
+        eng.run_waves(64)
+        recs += eng.drain_finished()
+        if any(r["game_seq"] == int(fx["game_seq"]) for r in recs):
+            break
+    eng.close()
+    return [r for r in recs if r["game_seq"] == int(fx["game_seq"])][0]
+
+
+@pytest.mark.parametrize("name", GUMBEL_CASES)
+def test_emu_gumbel_engine_matches_reference_fixture(emu_lib, name):
+    """Gumbel search (sequential halving + completed-Q selection) on the emulation build vs the reference's own output."""
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert_matches_fixture(play_gumbel_fixture(fx, emu_lib), fx)

@@ -113,3 +113,43 @@ def test_full_size_invariants():
     st = eng.stats()["game_stats"]
     assert st[2] >= 512 and st[3] + st[4] + st[5] == st[2] and st[0] <= 42
     eng.close()
+
+
+GUMBEL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_gumbel_*.npz")))
+
+
+@pytest.mark.parametrize("name", GUMBEL_CASES)
+def test_hip_gumbel_engine_matches_reference_fixture(name):
+    from grok_alpha_zero_amd.engine import SEARCH_GUMBEL
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    seq = int(fx["game_seq"])
+    eng = _engine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), 0, 0, 0.0, 0.0, int(fx["seed"]),
+                  slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8, search=SEARCH_GUMBEL,
+                  gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]))
+    recs = _play_until(eng, lambda rs: any(r["game_seq"] == seq for r in rs))
+    r = [x for x in recs if x["game_seq"] == seq][0]
+    assert r["T"] == len(fx["actions"])
+    for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies"):
+        np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
+    np.testing.assert_array_equal(r["values"], fx["values"].reshape(-1))
+    eng.close()
+
+
+@pytest.mark.parametrize("game,G,n,max_actions,m", [("Connect4", 512, 32, 42, 7), ("TicTacToe", 64, 16, 9, 4), ("Gomoku", 8, 48, 8, 16)])
+def test_hip_gumbel_matches_oracle_many_games(oracle, game, G, n, max_actions, m):
+    """BASELINE config 5 shape (Connect4, n = 32, m = 7) on many concurrent games vs the oracle, bit-exact."""
+    from grok_alpha_zero_amd.engine import SEARCH_GUMBEL
+    eng = _engine(game, G, n, max_actions, 0, 0, 0.0, 0.0, seed=31, hash_salt=13, slot_offset=500, ring_capacity=4 * G,
+                  search=SEARCH_GUMBEL, gumbel_m=m, c_visit=50.0, c_scale=1.0)
+    recs = _play_until(eng, lambda rs: len({r["slot"] for r in rs if r["game_seq"] == 0}) == G)
+    checked = 0
+    for r in recs:
+        if r["game_seq"] != 0:
+            continue
+        o = oracle.selfplay_game_gumbel(game, n, max_actions, m, 50.0, 1.0, 31, r["slot"], 0, hash_salt=13)
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
+        checked += 1
+    assert checked == G
+    eng.close()
