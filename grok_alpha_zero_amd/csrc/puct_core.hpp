@@ -69,6 +69,7 @@ template <class G> struct Scratch {   // per-wave LDS
     float aux[G::APAD];
     double gam[G::APAD];
     PathEnt path[PATH_CAP];
+    uint32_t node[(NodeLayout<G>::OFF_BOARD + 3) / 4];   // header + child arrays of the node being scored (one HBM round trip per level)
 };
 
 template <class T> GAZ_DEV T uni(T v) {
@@ -343,7 +344,16 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
     node = ts.root; depth = 0;
     uint64_t pv = ts.root_visits;
     for (;;) {
-        NodeRef<G> nd = node_at(E, g, t, node);
+        // Stage the node's header + N/W/P/child/action blocks in LDS with ONE coalesced read of the record, so a level
+        // of the descent costs one dependent HBM/L2 round trip instead of three (header -> stats -> chosen child).
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(node_at(E, g, t, node).p);
+            constexpr int NW = (NodeLayout<G>::OFF_BOARD + 3) / 4;
+            wave_sync();
+            for (int i = lane_id(); i < NW; i += WAVE) S.node[i] = src[i];
+            wave_sync();
+        }
+        NodeRef<G> nd{reinterpret_cast<uint8_t*>(S.node)};
         const NodeHdr h = *nd.hdr();
         const int n_actions = uni((int)h.n_actions), n_children = uni((int)h.n_children);
         if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return -1; }
