@@ -71,12 +71,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // BM rows per workgroup, WM x WN waves each owning TM x TN MFMA tiles of 32x32; the weight stream is cut into
 // 9 * KSPLIT slices of CIN / KSPLIT input channels.  OCC = workgroups per CU the LDS budget is sized for.
-template <int CIN, int BN, int BM, int WM, int WN, int TM, int TN, int KSPLIT, int OCC, int EPI>
+template <int CIN, int BN, int BM, int WM, int WN, int TM, int TN, int KSPLIT, int OCC, int EPI, int NTAPS = 9>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3x3(ConvArgs a) {
     constexpr int CONV_BM = BM, CONV_THREADS = WM * WN * 64;
     static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int SLOTS = CIN / 8;                 // 16-byte slots per row (16 for CIN = 128)
-    static_assert(SLOTS == 16, "swizzle below assumes 16 slots per row");
+    static_assert(SLOTS == 16 || SLOTS == 32, "swizzle: XOR of the low four slot bits with row & 15");
+    static_assert(NTAPS == 9 || NTAPS == 1, "3x3 or 1x1 (centre tap only)");
     constexpr int AROWS = BM + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1;
     constexpr int KSS = CIN / 16 / KSPLIT;         // k-steps per weight slice
     constexpr int BSL = BN * SLOTS / KSPLIT;       // 16-byte units per weight slice
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
     // slot s = s' ^ (row & 15) of that row, so a later read of logical slot s at s ^ (row & 15) finds it.
     const int n_aslots = (CONV_BM + 2 * halo) * SLOTS;
     for (int base = wave * 64; base < n_aslots; base += CONV_THREADS) {
-        const int i = base + lane, lr = i >> 4, sp = i & 15;
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
         long gr = m0 - halo + lr;
         gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);     // rows outside the tensor are never selected
         __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
 
     __syncthreads();                                // image + slice 0 have landed (the barrier drains the DMA queue)
 
-    for (int sl = 0; sl < 9 * KSPLIT; ++sl) {
-        const int tap = sl / KSPLIT, ks0 = (sl % KSPLIT) * KSS;
+    for (int sl = 0; sl < NTAPS * KSPLIT; ++sl) {
+        const int tap = NTAPS == 9 ? sl / KSPLIT : 4, ks0 = (sl % KSPLIT) * KSS;
         const uint4* Bc = Bs + (sl & 1) * BSL;
-        if (sl + 1 < 9 * KSPLIT && !(a.dbg & 1)) {  // DMA of the next slice into the other buffer, in flight during the MFMAs
+        if (sl + 1 < NTAPS * KSPLIT && !(a.dbg & 1)) {  // DMA of the next slice into the other buffer, in flight during the MFMAs
             uint4* Bn = Bs + ((sl + 1) & 1) * BSL;
             const uint4* wsrc = w4 + (size_t)(sl + 1) * BSL;
             for (int base = wave * 64; base < BSL; base += CONV_THREADS)
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
 }
 
 // Host: [9][cout][cin] (export order) -> [9][cin/16][2][cout][8] (MFMA B-fragment order).
-inline void arrange_conv_weights(const float* src, int cout, int cin, bf16_t* dst, bf16_t (*cvt)(float)) {
-    for (int tap = 0; tap < 9; ++tap)
+inline void arrange_conv_weights(const float* src, int cout, int cin, bf16_t* dst, bf16_t (*cvt)(float), int ntaps = 9) {
+    for (int tap = 0; tap < ntaps; ++tap)
         for (int n = 0; n < cout; ++n)
             for (int k = 0; k < cin; ++k) {
                 const int ks = k / 16, half = (k % 16) / 8, j = k % 8;

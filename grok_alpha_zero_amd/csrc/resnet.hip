@@ -20,6 +20,7 @@
 #include <vector>
 #include "evaluator.hpp"
 #include "conv3x3.hpp"
+#include "netops.hpp"
 
 namespace gaz {
 
@@ -216,7 +217,7 @@ struct ResNetEvaluator : Evaluator {
         a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1;
         a.scaleB = sB; a.shiftB = tB; a.out2 = out2; a.M = M; a.H = H; a.W = W;
         { const char* d = getenv("GAZ_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
-        static const int variant = getenv("GAZ_CONV_VARIANT") ? atoi(getenv("GAZ_CONV_VARIANT")) : 1;
+        static const int variant = getenv("GAZ_CONV_VARIANT") ? atoi(getenv("GAZ_CONV_VARIANT")) : 0;
         if (variant == 0) {          // 256 rows / 512 threads / whole-tap slices, one workgroup per CU
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
             hipLaunchKernelGGL((k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), dim3((M + 255) / 256), dim3(512), lds, s, a);
@@ -273,8 +274,200 @@ struct ResNetEvaluator : Evaluator {
     }
 };
 
+// ------------------------------------------------------------------------------------------ Gomoku / TicTacToe
+// Same trunk kernel (k_conv3x3) where the layer is 128-wide; the 256-channel first block of the Gomoku net uses the
+// CIN = 256 / 128-row instantiation (3x3 conv1 and the 1x1 residual projection); narrow layers go through netops.hpp.
+struct GenericEvaluator : Evaluator {
+    int H, W, C, A, HW, blocks, F, nmax, logits; bool gomoku;
+    std::map<std::string, float*> f32; std::map<std::string, bf16_t*> b16; std::map<std::string, const gaz_tensor*> by;
+    std::vector<void*> allocs; bool loaded = false; std::string lerr;
+    bf16_t *X0 = nullptr, *A0 = nullptr, *X = nullptr, *Aa = nullptr, *Hh = nullptr, *Va = nullptr, *PH = nullptr, *VH = nullptr;
+    float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
+    std::vector<hipEvent_t> tev; int trunk_convs = 0;
+
+    ~GenericEvaluator() override { for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e); }
+    template <class T> T* dalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n + 64) * sizeof(T)) != hipSuccess) return nullptr; allocs.push_back(p); return (T*)p; }
+    bool ready() const override { return loaded; }
+
+    const gaz_tensor* need(const std::string& name, int64_t numel) {
+        auto it = by.find(name);
+        if (it == by.end()) { lerr = "missing tensor " + name; return nullptr; }
+        if (it->second->numel != numel) { lerr = "tensor " + name + ": " + std::to_string(it->second->numel) + " elements, expected " + std::to_string(numel); return nullptr; }
+        return it->second;
+    }
+    bool up(const std::string& name, int64_t numel) {
+        const gaz_tensor* g = need(name, numel); if (!g) return false;
+        float* d = dalloc<float>(numel); if (!d) { lerr = "hipMalloc"; return false; }
+        hipMemcpy(d, g->data, numel * 4, hipMemcpyHostToDevice); f32[name] = d; return true;
+    }
+    bool up_mfma(const std::string& name, int cout, int cin, int ntaps) {
+        const int64_t numel = (int64_t)ntaps * cout * cin;
+        const gaz_tensor* g = need(name, numel); if (!g) return false;
+        std::vector<bf16_t> h(numel);
+        arrange_conv_weights(g->data, cout, cin, h.data(), f2bf_host, ntaps);
+        bf16_t* d = dalloc<bf16_t>(numel); if (!d) { lerr = "hipMalloc"; return false; }
+        hipMemcpy(d, h.data(), numel * 2, hipMemcpyHostToDevice); b16[name] = d; return true;
+    }
+
+    int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) override {
+        by.clear(); for (int i = 0; i < n; ++i) by[t[i].name] = &t[i];
+        const int SC = gomoku ? 256 : 128, K = gomoku ? 3 : 5;
+        bool ok = up("stem.w", (int64_t)K * K * SC * C) && up("stem.scale", SC) && up("stem.shift", SC);
+        for (int i = 0; ok && i < blocks; ++i) {
+            const std::string b = "block" + std::to_string(i); const int cin = i == 0 ? SC : F;
+            ok = up(b + ".bn1.scale", cin) && up(b + ".bn1.shift", cin) && up(b + ".conv1.scale", F) && up(b + ".conv1.shift", F) && up(b + ".conv2.bias", F);
+            if (!ok) break;
+            if (gomoku) ok = up_mfma(b + ".conv1.w", F, cin, 9) && up_mfma(b + ".conv2.w", F, F, 9);
+            else ok = up(b + ".conv1.w", 9LL * F * cin) && up(b + ".conv2.w", 9LL * F * F);
+            if (ok && cin != F) ok = (gomoku ? up_mfma(b + ".proj.w", F, cin, 1) : up(b + ".proj.w", (int64_t)F * cin)) && up(b + ".proj.bias", F);
+        }
+        if (ok && gomoku) {
+            ok = up("p.bn0.scale", F) && up("p.bn0.shift", F) && up("v.bn0.scale", F) && up("v.bn0.shift", F) &&
+                 up_mfma("p.c1.w", 32, F, 9) && up("p.c1.scale", 32) && up("p.c1.shift", 32) && up_mfma("v.c1.w", 32, F, 9) && up("v.c1.scale", 32) && up("v.c1.shift", 32) &&
+                 up("p.c2.w", 9 * 8 * 32) && up("p.c2.bias", 8) && up("p.bn2.scale", HW * 8) && up("p.bn2.shift", HW * 8) &&
+                 up("v.c2.w", 4 * 32) && up("v.c2.bias", 4) && up("v.bn2.scale", HW * 4) && up("v.bn2.shift", HW * 4) &&
+                 up("p.d1.w", (int64_t)HW * 8 * 512) && up("p.d1.scale", 512) && up("p.d1.shift", 512) && up("p.d2.w", 512LL * A) && up("p.d2.bias", A) &&
+                 up("v.d1.w", (int64_t)HW * 4 * 256) && up("v.d1.scale", 256) && up("v.d1.shift", 256) && up("v.d2.w", 256 * 128) && up("v.d2.scale", 128) && up("v.d2.shift", 128) &&
+                 up("v.d3.w", 128) && up("v.d3.bias", 1);
+        } else if (ok) {
+            ok = up("p.c.w", 8 * F) && up("p.c.scale", 8) && up("p.c.shift", 8) && up("v.c.w", 4 * F) && up("v.c.scale", 4) && up("v.c.shift", 4) &&
+                 up("p.d1.w", HW * 8 * 128) && up("p.d1.bias", 128) && up("p.d2.w", 128 * 64) && up("p.d2.bias", 64) && up("p.d3.w", 64 * A) && up("p.d3.bias", A) &&
+                 up("v.d1.w", HW * 4 * 128) && up("v.d1.bias", 128) && up("v.d2.w", 128 * 64) && up("v.d2.bias", 64) && up("v.d3.w", 64) && up("v.d3.bias", 1);
+        }
+        hipStreamSynchronize(s);
+        if (!ok) { *err = lerr; return 1; }
+        loaded = true; return 0;
+    }
+
+    template <int CIN, int NT> void conv_mfma(hipStream_t s, const bf16_t* in, const bf16_t* w, const float* sA, const float* tA, const bf16_t* res,
+                                               bf16_t* out1, int act1, const float* sB, const float* tB, bf16_t* out2, int M) {
+        ConvArgs a; memset(&a, 0, sizeof(a));
+        a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1; a.scaleB = sB; a.shiftB = tB; a.out2 = out2;
+        a.M = M; a.H = H; a.W = W;
+        if (CIN == 128) {
+            const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
+            hipLaunchKernelGGL((k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, NT>), dim3((M + 255) / 256), dim3(512), lds, s, a);
+        } else {
+            const size_t lds = conv_lds_bytes<256, 128, 128, 4>();
+            hipLaunchKernelGGL((k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, NT>), dim3((M + 127) / 128), dim3(256), lds, s, a);
+        }
+    }
+    void conv_mfma32(hipStream_t s, const bf16_t* in, const bf16_t* w, const float* sA, const float* tA, bf16_t* out1, int M) {
+        ConvArgs a; memset(&a, 0, sizeof(a));
+        a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.out1 = out1; a.act1 = ACT_RELU; a.M = M; a.H = H; a.W = W;
+        const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
+        hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 0, 9>), dim3((M + 255) / 256), dim3(512), lds, s, a);
+    }
+    void conv_direct(hipStream_t s, const bf16_t* in, const float* w, int cin, int cout, int K, const float* sA, const float* tA, const bf16_t* res,
+                     bf16_t* out1, int act1, const float* sB, const float* tB, bf16_t* out2, float* flat, const float* fs, const float* ft,
+                     int flat_act, int M) {
+        ConvDirectArgs a; memset(&a, 0, sizeof(a));
+        a.in = in; a.w = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1; a.scaleB = sB; a.shiftB = tB; a.out2 = out2;
+        a.flat = flat; a.fs = fs; a.ft = ft; a.flat_act = flat_act; a.M = M; a.H = H; a.W = W; a.CIN = cin; a.COUT = cout; a.K = K;
+        const long items = (long)M * cout;
+        hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+    }
+    void dense(hipStream_t s, const float* in, const std::string& w, const float* sc, const float* sh, float* out, int n, int K, int N, int act) {
+        hipLaunchKernelGGL(k_dense, dim3((n + 7) / 8), dim3(128), (size_t)8 * K * 4, s, in, f32[w], sc, sh, out, n, K, N, act);
+    }
+    float* g(const std::string& k) { return f32[k]; }
+
+    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) override {
+        if (!loaded) return;
+        const int M = n * HW, SC = gomoku ? 256 : 128;
+        StemGenArgs st; memset(&st, 0, sizeof(st));
+        st.in = in; st.w = g("stem.w"); st.scale = g("stem.scale"); st.shift = g("stem.shift"); st.scaleB = g("block0.bn1.scale"); st.shiftB = g("block0.bn1.shift");
+        st.out1 = X0; st.out2 = A0; st.M = M; st.H = H; st.W = W; st.CIN = C; st.COUT = SC; st.K = gomoku ? 3 : 5; st.act = gomoku ? NACT_RELU : NACT_GELU;
+        hipLaunchKernelGGL(k_stem_generic, dim3((unsigned)(((long)M * (SC / 8) + 255) / 256)), dim3(256), 0, s, st);
+        hipEvent_t e0 = 0, e1 = 0;
+        if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
+        trunk_convs = 0;
+        for (int i = 0; i < blocks; ++i) {
+            const std::string b = "block" + std::to_string(i), nb = "block" + std::to_string(i + 1);
+            const bool first = i == 0, last = i + 1 == blocks;
+            const bf16_t* ain = first ? A0 : Aa;
+            const float* sB = last ? (gomoku ? g("p.bn0.scale") : nullptr) : g(nb + ".bn1.scale");
+            const float* tB = last ? (gomoku ? g("p.bn0.shift") : nullptr) : g(nb + ".bn1.shift");
+            bf16_t* o2 = sB ? Aa : nullptr;
+            if (gomoku) {
+                if (first) {
+                    conv_mfma<256, 9>(s, ain, b16[b + ".conv1.w"], g(b + ".conv1.scale"), g(b + ".conv1.shift"), nullptr, Hh, ACT_RELU, nullptr, nullptr, nullptr, M);
+                    conv_mfma<256, 1>(s, X0, b16[b + ".proj.w"], nullptr, g(b + ".proj.bias"), nullptr, X, ACT_NONE, nullptr, nullptr, nullptr, M);
+                } else {
+                    conv_mfma<128, 9>(s, ain, b16[b + ".conv1.w"], g(b + ".conv1.scale"), g(b + ".conv1.shift"), nullptr, Hh, ACT_RELU, nullptr, nullptr, nullptr, M);
+                    trunk_convs++;
+                }
+                conv_mfma<128, 9>(s, Hh, b16[b + ".conv2.w"], nullptr, g(b + ".conv2.bias"), X, X, ACT_NONE, sB, tB, o2, M);
+                trunk_convs++;
+            } else {
+                const int cin = first ? SC : F;
+                conv_direct(s, ain, g(b + ".conv1.w"), cin, F, 3, g(b + ".conv1.scale"), g(b + ".conv1.shift"), nullptr, Hh, NACT_RELU, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, 0, M);
+                if (first) conv_direct(s, X0, g(b + ".proj.w"), cin, F, 1, nullptr, g(b + ".proj.bias"), nullptr, X, NACT_NONE, nullptr, nullptr, nullptr,
+                                       nullptr, nullptr, nullptr, 0, M);
+                conv_direct(s, Hh, g(b + ".conv2.w"), F, F, 3, nullptr, g(b + ".conv2.bias"), X, X, NACT_NONE, sB, tB, o2, nullptr, nullptr, nullptr, 0, M);
+            }
+        }
+        if (timing) hipEventRecord(e1, s);
+        if (gomoku) {
+            hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, X, g("v.bn0.scale"), g("v.bn0.shift"), Va, (long)M * F / 8, F);
+            conv_mfma32(s, Aa, b16["p.c1.w"], g("p.c1.scale"), g("p.c1.shift"), PH, M);
+            conv_mfma32(s, Va, b16["v.c1.w"], g("v.c1.scale"), g("v.c1.shift"), VH, M);
+            conv_direct(s, PH, g("p.c2.w"), 32, 8, 3, nullptr, g("p.c2.bias"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, pfeat, g("p.bn2.scale"), g("p.bn2.shift"), NACT_RELU, M);
+            conv_direct(s, VH, g("v.c2.w"), 32, 4, 1, nullptr, g("v.c2.bias"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, vfeat, g("v.bn2.scale"), g("v.bn2.shift"), NACT_RELU, M);
+            dense(s, pfeat, "p.d1.w", g("p.d1.scale"), g("p.d1.shift"), pd1, n, HW * 8, 512, NACT_RELU);
+            dense(s, pd1, "p.d2.w", nullptr, g("p.d2.bias"), plog, n, 512, A, NACT_NONE);
+            dense(s, vfeat, "v.d1.w", g("v.d1.scale"), g("v.d1.shift"), vd1, n, HW * 4, 256, NACT_RELU);
+            dense(s, vd1, "v.d2.w", g("v.d2.scale"), g("v.d2.shift"), vd2, n, 256, 128, NACT_RELU);
+            dense(s, vd2, "v.d3.w", nullptr, g("v.d3.bias"), value, n, 128, 1, NACT_TANH);
+        } else {
+            conv_direct(s, X, g("p.c.w"), F, 8, 1, g("p.c.scale"), g("p.c.shift"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, pfeat, nullptr, nullptr, NACT_NONE, M);
+            conv_direct(s, X, g("v.c.w"), F, 4, 1, g("v.c.scale"), g("v.c.shift"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, vfeat, nullptr, nullptr, NACT_NONE, M);
+            dense(s, pfeat, "p.d1.w", nullptr, g("p.d1.bias"), pd1, n, HW * 8, 128, NACT_RELU);
+            dense(s, pd1, "p.d2.w", nullptr, g("p.d2.bias"), pd2, n, 128, 64, NACT_NONE);
+            dense(s, pd2, "p.d3.w", nullptr, g("p.d3.bias"), plog, n, 64, A, NACT_NONE);
+            dense(s, vfeat, "v.d1.w", nullptr, g("v.d1.bias"), vd1, n, HW * 4, 128, NACT_NONE);
+            dense(s, vd1, "v.d2.w", nullptr, g("v.d2.bias"), vd2, n, 128, 64, NACT_RELU);
+            dense(s, vd2, "v.d3.w", nullptr, g("v.d3.bias"), value, n, 64, 1, NACT_TANH);
+        }
+        hipLaunchKernelGGL(k_softmax_rows, dim3(n), dim3(64), 0, s, plog, policy, n, A, logits);
+    }
+    void timing_reset() override { for (auto e : tev) hipEventDestroy(e); tev.clear(); }
+    void timing_get(double* ms, int64_t* launches) override {
+        double t = 0;
+        for (size_t i = 0; i + 1 < tev.size(); i += 2) { float a = 0; hipEventElapsedTime(&a, tev[i], tev[i + 1]); t += a; }
+        *ms = t; *launches = (int64_t)(tev.size() / 2) * (trunk_convs > 0 ? trunk_convs : 1);
+    }
+};
+
+static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, bool gomoku, std::string* err) {
+    if (gomoku && cfg.net_filters != 128) { *err = "Gomoku net: net_filters must be 128"; return nullptr; }
+    if (!gomoku && cfg.net_filters != 64 && cfg.net_filters != 0 && cfg.net_filters != 128) { *err = "TicTacToe net uses 64 filters"; return nullptr; }
+    if (cfg.net_blocks < 1 || cfg.net_blocks > 64) { *err = "net_blocks out of range"; return nullptr; }
+    GenericEvaluator* e = new GenericEvaluator();
+    e->H = H; e->W = W; e->C = C; e->A = A; e->HW = H * W; e->blocks = cfg.net_blocks; e->F = gomoku ? 128 : 64; e->nmax = cfg.n_games;
+    e->logits = cfg.policy_is_logits; e->gomoku = gomoku;
+    const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
+    e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
+    e->Hh = e->dalloc<bf16_t>(M * F); e->Va = e->dalloc<bf16_t>(M * F); e->PH = e->dalloc<bf16_t>(M * 32); e->VH = e->dalloc<bf16_t>(M * 32);
+    e->pfeat = e->dalloc<float>(n * e->HW * 8); e->vfeat = e->dalloc<float>(n * e->HW * 8); e->pd1 = e->dalloc<float>(n * 512); e->vd1 = e->dalloc<float>(n * 256);
+    e->pd2 = e->dalloc<float>(n * 128); e->vd2 = e->dalloc<float>(n * 128); e->plog = e->dalloc<float>(n * 256);
+    if (!e->X0 || !e->A0 || !e->X || !e->Aa || !e->Hh || !e->Va || !e->PH || !e->VH || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1 || !e->pd2 || !e->vd2 || !e->plog) {
+        *err = "hipMalloc failed"; delete e; return nullptr;
+    }
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_dense, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return e;
+}
+
 Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err) {
-    if (!(H == 6 && W == 7 && C == 4)) { *err = "the HIP ResNet evaluator is built for the Connect4 network in this version"; return nullptr; }
+    if (H == 15 && W == 15) return make_generic_evaluator(cfg, H, W, C, A, true, err);
+    if (H == 3 && W == 3) return make_generic_evaluator(cfg, H, W, C, A, false, err);
+    if (!(H == 6 && W == 7 && C == 4)) { *err = "no network is defined for this board"; return nullptr; }
     if (cfg.net_filters != 128) { *err = "net_filters must be 128"; return nullptr; }
     if (cfg.net_blocks < 1 || cfg.net_blocks > 64) { *err = "net_blocks out of range"; return nullptr; }
     ResNetEvaluator* e = new ResNetEvaluator();

@@ -185,3 +185,150 @@ def flops_per_position(num_blocks=6, filters=128, H=6, W=7):
     stem = 2 * hw * 9 * 4 * 128
     heads = 2 * hw * 9 * filters * 16 + 2 * 2 * (hw * 8 * 128 + 128 * 64) + 2 * (64 * 7 + 64)
     return dict(trunk=trunk, stem=stem, heads=heads, total=trunk + stem + heads)
+
+
+# =====================================================================================================================
+# Gomoku and TicTacToe networks (same building blocks; exported as generic layer tensors for csrc/resnet.hip)
+# =====================================================================================================================
+def _conv_w(c):
+    """[kh,kw,cin,cout] -> [kh*kw, cout, cin] float32 (tap-major, the layout every HIP conv kernel reads)."""
+    k = c.weight.shape[0] * c.weight.shape[1]
+    return c.weight.detach().permute(0, 1, 3, 2).reshape(k, c.weight.shape[3], c.weight.shape[2]).contiguous().numpy()
+
+
+def _np(d):
+    return {k: np.ascontiguousarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, np.float32) for k, v in d.items()}
+
+
+class GomokuNet(nn.Module):
+    """Gomoku/Build_Model.py:10-88.  Input [B,15,15,2]; stem Conv3x3 -> 256 (hard-coded, :21) + BN + ReLU; N pre-activation
+    blocks of `num_filters` (the first one projects 256 -> num_filters with a 1x1 conv); policy: BN, ReLU, Conv3x3->32, BN,
+    ReLU, Conv3x3->8, flatten(1800), BN, ReLU, Dense512, BN, ReLU, Dense225, softmax(f64); value: BN, ReLU, Conv3x3->32, BN,
+    ReLU, Conv1x1->4, flatten(900), BN, ReLU, Dense256, BN, ReLU, Dense128, BN, ReLU, Dense1, tanh."""
+    H, W, C, A = 15, 15, 2, 225
+
+    def __init__(self, num_resnet_layers=10, num_filters=128, policy_head="softmax", seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.policy_head = policy_head
+        self.stem = _ConvNHWC(2, 256, 3); self.stem_bn = _BN(256)
+        blocks, cin = [], 256
+        for _ in range(num_resnet_layers):
+            blocks.append(ResNetBlock(cin, num_filters)); cin = num_filters
+        self.blocks = nn.ModuleList(blocks)
+        F = num_filters
+        self.p_bn0 = _BN(F); self.p_c1 = _ConvNHWC(F, 32, 3); self.p_bn1 = _BN(32); self.p_c2 = _ConvNHWC(32, 8, 3)
+        self.p_bn2 = _BN(1800); self.p_d1 = _Dense(1800, 512); self.p_bn3 = _BN(512); self.p_d2 = _Dense(512, 225)
+        self.v_bn0 = _BN(F); self.v_c1 = _ConvNHWC(F, 32, 3); self.v_bn1 = _BN(32); self.v_c2 = _ConvNHWC(32, 4, 1)
+        self.v_bn2 = _BN(900); self.v_d1 = _Dense(900, 256); self.v_bn3 = _BN(256); self.v_d2 = _Dense(256, 128)
+        self.v_bn4 = _BN(128); self.v_d3 = _Dense(128, 1)
+
+    randomize_bn = Connect4Net.randomize_bn
+
+    def forward(self, x):
+        x = F.relu(self.stem_bn(self.stem(x.float())))
+        for b in self.blocks:
+            x = b(x)
+        B = x.shape[0]
+        p = self.p_c2(F.relu(self.p_bn1(self.p_c1(F.relu(self.p_bn0(x)))))).reshape(B, -1)
+        p = self.p_d2(F.relu(self.p_bn3(self.p_d1(F.relu(self.p_bn2(p))))))
+        if self.policy_head == "softmax":
+            p = torch.softmax(p.double(), -1).float()
+        v = self.v_c2(F.relu(self.v_bn1(self.v_c1(F.relu(self.v_bn0(x)))))).reshape(B, -1)
+        v = F.relu(self.v_bn3(self.v_d1(F.relu(self.v_bn2(v)))))
+        v = torch.tanh(self.v_d3(F.relu(self.v_bn4(self.v_d2(v)))))
+        return p, v
+
+    @torch.no_grad()
+    def export_engine_weights(self):
+        o = {}
+        s, t = self.stem_bn.affine()
+        o["stem.w"] = _conv_w(self.stem); o["stem.scale"] = s; o["stem.shift"] = self.stem.bias * s + t
+        for i, b in enumerate(self.blocks):
+            s1, t1 = b.bn1.affine(); s2, t2 = b.bn2.affine()
+            o[f"block{i}.bn1.scale"] = s1; o[f"block{i}.bn1.shift"] = t1
+            o[f"block{i}.conv1.w"] = _conv_w(b.conv1); o[f"block{i}.conv1.scale"] = s2; o[f"block{i}.conv1.shift"] = b.conv1.bias * s2 + t2
+            o[f"block{i}.conv2.w"] = _conv_w(b.conv2); o[f"block{i}.conv2.bias"] = b.conv2.bias
+            if b.proj is not None:
+                o[f"block{i}.proj.w"] = _conv_w(b.proj); o[f"block{i}.proj.bias"] = b.proj.bias
+        # heads: relu(bn0(x)) per head; first convs of both heads as ONE 3x3 conv with 64 outputs (0-31 policy, 32-63 value)
+        sp, tp = self.p_bn0.affine(); sv, tv = self.v_bn0.affine()
+        o["p.bn0.scale"] = sp; o["p.bn0.shift"] = tp; o["v.bn0.scale"] = sv; o["v.bn0.shift"] = tv
+        s1p, t1p = self.p_bn1.affine(); s1v, t1v = self.v_bn1.affine()
+        o["p.c1.w"] = _conv_w(self.p_c1); o["p.c1.scale"] = s1p; o["p.c1.shift"] = self.p_c1.bias * s1p + t1p
+        o["v.c1.w"] = _conv_w(self.v_c1); o["v.c1.scale"] = s1v; o["v.c1.shift"] = self.v_c1.bias * s1v + t1v
+        s2p, t2p = self.p_bn2.affine(); s2v, t2v = self.v_bn2.affine()
+        o["p.c2.w"] = _conv_w(self.p_c2); o["p.c2.bias"] = self.p_c2.bias; o["p.bn2.scale"] = s2p; o["p.bn2.shift"] = t2p
+        o["v.c2.w"] = _conv_w(self.v_c2); o["v.c2.bias"] = self.v_c2.bias; o["v.bn2.scale"] = s2v; o["v.bn2.shift"] = t2v
+        s3p, t3p = self.p_bn3.affine()
+        o["p.d1.w"] = self.p_d1.weight; o["p.d1.scale"] = s3p; o["p.d1.shift"] = self.p_d1.bias * s3p + t3p
+        o["p.d2.w"] = self.p_d2.weight; o["p.d2.bias"] = self.p_d2.bias
+        s3v, t3v = self.v_bn3.affine(); s4v, t4v = self.v_bn4.affine()
+        o["v.d1.w"] = self.v_d1.weight; o["v.d1.scale"] = s3v; o["v.d1.shift"] = self.v_d1.bias * s3v + t3v
+        o["v.d2.w"] = self.v_d2.weight; o["v.d2.scale"] = s4v; o["v.d2.shift"] = self.v_d2.bias * s4v + t4v
+        o["v.d3.w"] = self.v_d3.weight; o["v.d3.bias"] = self.v_d3.bias
+        return _np(o)
+
+
+class TicTacToeNet(nn.Module):
+    """TicTacToe/Build_Model.py:8-69.  Input [B,3,3,2]; stem Conv5x5 -> 128 + BN + GELU; N blocks of 64 filters (first one
+    projects 128 -> 64); policy: Conv1x1->8, BN, flatten(72), Dense128, ReLU, Dense64, Dense9, softmax; value: Conv1x1->4, BN,
+    flatten(36), Dense128, Dense64, ReLU, Dense1, tanh."""
+    H, W, C, A = 3, 3, 2, 9
+
+    def __init__(self, num_resnet_layers=2, policy_head="softmax", seed=0, final_std=0.05):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.policy_head = policy_head
+        self.stem = _ConvNHWC(2, 128, 5); self.stem_bn = _BN(128)
+        blocks, cin = [], 128
+        for _ in range(num_resnet_layers):
+            blocks.append(ResNetBlock(cin, 64)); cin = 64
+        self.blocks = nn.ModuleList(blocks)
+        self.p_conv = _ConvNHWC(cin, 8, 1); self.p_bn = _BN(8); self.p_d1 = _Dense(72, 128); self.p_d2 = _Dense(128, 64)
+        self.p_d3 = _Dense(64, 9, zeros=True)
+        self.v_conv = _ConvNHWC(cin, 4, 1); self.v_bn = _BN(4); self.v_d1 = _Dense(36, 128); self.v_d2 = _Dense(128, 64)
+        self.v_d3 = _Dense(64, 1, zeros=True)
+        if final_std:
+            g = torch.Generator().manual_seed(seed + 1)
+            with torch.no_grad():
+                self.p_d3.weight.copy_(final_std * torch.randn(64, 9, generator=g)); self.v_d3.weight.copy_(final_std * torch.randn(64, 1, generator=g))
+
+    randomize_bn = Connect4Net.randomize_bn
+
+    def forward(self, x):
+        x = F.gelu(self.stem_bn(self.stem(x.float())))
+        for b in self.blocks:
+            x = b(x)
+        B = x.shape[0]
+        p = self.p_bn(self.p_conv(x)).reshape(B, -1)
+        p = self.p_d3(self.p_d2(F.relu(self.p_d1(p))))
+        if self.policy_head == "softmax":
+            p = torch.softmax(p, -1)
+        v = self.v_bn(self.v_conv(x)).reshape(B, -1)
+        v = torch.tanh(self.v_d3(F.relu(self.v_d2(self.v_d1(v)))))
+        return p, v
+
+    @torch.no_grad()
+    def export_engine_weights(self):
+        o = {}
+        s, t = self.stem_bn.affine()
+        o["stem.w"] = _conv_w(self.stem); o["stem.scale"] = s; o["stem.shift"] = self.stem.bias * s + t
+        for i, b in enumerate(self.blocks):
+            s1, t1 = b.bn1.affine(); s2, t2 = b.bn2.affine()
+            o[f"block{i}.bn1.scale"] = s1; o[f"block{i}.bn1.shift"] = t1
+            o[f"block{i}.conv1.w"] = _conv_w(b.conv1); o[f"block{i}.conv1.scale"] = s2; o[f"block{i}.conv1.shift"] = b.conv1.bias * s2 + t2
+            o[f"block{i}.conv2.w"] = _conv_w(b.conv2); o[f"block{i}.conv2.bias"] = b.conv2.bias
+            if b.proj is not None:
+                o[f"block{i}.proj.w"] = _conv_w(b.proj); o[f"block{i}.proj.bias"] = b.proj.bias
+        sp, tp = self.p_bn.affine(); sv, tv = self.v_bn.affine()
+        o["p.c.w"] = _conv_w(self.p_conv); o["p.c.scale"] = sp; o["p.c.shift"] = self.p_conv.bias * sp + tp
+        o["v.c.w"] = _conv_w(self.v_conv); o["v.c.scale"] = sv; o["v.c.shift"] = self.v_conv.bias * sv + tv
+        for pre in ("p", "v"):
+            for k in (1, 2, 3):
+                d = getattr(self, f"{pre}_d{k}")
+                o[f"{pre}.d{k}.w"] = d.weight; o[f"{pre}.d{k}.bias"] = d.bias
+        return _np(o)
+
+
+NETS = {"Connect4": Connect4Net, "Gomoku": GomokuNet, "TicTacToe": TicTacToeNet}

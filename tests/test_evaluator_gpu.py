@@ -109,3 +109,28 @@ def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
 
 def iters_fix(i):
     return 200   # _mk builds the engine with run_iterations = 200
+
+
+@pytest.mark.parametrize("game,blocks,n", [("Gomoku", 2, 9), ("Gomoku", 10, 40), ("TicTacToe", 2, 300)])
+def test_gomoku_tictactoe_evaluators_match_torch_fp32(game, blocks, n):
+    """Gomoku (stem 256, projected first block, 32/8/4-channel head convs, Dense512/225) and TicTacToe (5x5 stem, 64-filter
+    blocks with projection, 1x1 heads) networks: HIP vs the fp32 PyTorch restatement.  bf16 trunk => tolerance test."""
+    import torch
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    rng = np.random.default_rng(blocks + n)
+    net = NETS[game](blocks).eval().randomize_bn()
+    H, W, C, A = net.H, net.W, net.C, net.A
+    eng = SelfPlayEngine(game, max(n, 8), 50, 9 if game == "TicTacToe" else 150, 2, 1, 1.25, 1.0, seed=1, evaluator=EVAL_RESNET,
+                         net_blocks=blocks, net_filters=128 if game == "Gomoku" else 64, ring_capacity=0)
+    eng.load_weights(net.export_engine_weights())
+    x = rng.integers(-1, 2, size=(n, H, W, C)).astype(np.int8)
+    x[..., 0] = rng.choice([-1, 1], size=(n, 1, 1))
+    pol, val, _ = eng.evaluate(x)
+    with torch.no_grad():
+        p_ref, v_ref = net(torch.from_numpy(x))
+    dp = np.abs(pol - p_ref.numpy()); dv = np.abs(val - v_ref.numpy().reshape(-1))
+    assert np.isfinite(pol).all() and np.allclose(pol.sum(1), 1.0, atol=1e-5)
+    assert dp.max() <= 6e-2 and dp.mean() <= 3e-3, (dp.max(), dp.mean())
+    assert dv.max() <= 0.15 and dv.mean() <= 2e-2, (dv.max(), dv.mean())
+    eng.close()
