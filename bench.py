@@ -27,9 +27,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
-    ap.add_argument("--sims", type=int, default=200, help="iteration_limit of every MCTS.run")
-    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--config", default="connect4", choices=["connect4", "gomoku", "gumbel"],
+                    help="connect4 = BASELINE configs[1] (headline); gomoku = configs[3]; gumbel = configs[4]")
+    ap.add_argument("--games", type=int, default=0, help="concurrent games per GPU (0 = the config's value)")
+    ap.add_argument("--sims", type=int, default=0, help="iteration_limit of every MCTS.run (0 = the config's value)")
+    ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--waves-per-step", type=int, default=400)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "hash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -62,8 +64,17 @@ def cpu_baseline(args, net):
                        f"oracle/ C restatement, sequential games, batch-1 PyTorch fp32 CPU evaluator ({cores} threads)")
 
 
+CONFIGS = {   # game, games/GPU, sims/move, blocks, max_actions, explore first/second, c_puct, alpha, search, m
+    "connect4": ("Connect4", 4096, 200, 6, 42, 8, 7, 2.5, 0.5, "puct", 0),
+    "gomoku": ("Gomoku", 2048, 400, 10, 150, 6, 4, 4.5, 0.05, "puct", 0),
+    "gumbel": ("Connect4", 8192, 32, 6, 42, 8, 7, 2.5, 0.5, "gumbel", 7),
+}
+
+
 def main():
     args = parse()
+    game, dG, dS, dB, max_actions, ef, es, cpuct, alpha, search, gm = CONFIGS[args.config]
+    args.games = args.games or dG; args.sims = args.sims or dS; args.blocks = args.blocks or dB
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,15 +85,17 @@ def main():
                                 device_id=torch.device("cuda", local) if torch.cuda.is_available() else None)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     torch.cuda.set_device(local)
-    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET, EVAL_HASH
-    from grok_alpha_zero_amd.net import Connect4Net, flops_per_position
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET, EVAL_HASH, SEARCH_GUMBEL, SEARCH_PUCT
+    from grok_alpha_zero_amd.net import NETS, flops_per_position
     from grok_alpha_zero_amd.parallel import reduce_stats
 
     G = args.games
-    net = Connect4Net(args.blocks, seed=0).eval()
-    eng = SelfPlayEngine("Connect4", G, args.sims, 42, 8, 7, 2.5, 0.5, seed=1234, slot_offset=rank * G, device=local,
+    gumbel = search == "gumbel"
+    net = NETS[game](args.blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval()
+    eng = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
                          evaluator=EVAL_RESNET if args.evaluator == "resnet" else EVAL_HASH, net_blocks=args.blocks,
-                         hash_salt=7, ring_capacity=0)
+                         hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
+                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel)
     if args.evaluator == "resnet":
         eng.load_weights(net.export_engine_weights())
 
@@ -120,22 +133,28 @@ def main():
     positions, games, evals, sims = (int(x) for x in total)
 
     if rank == 0:
-        fl = flops_per_position(args.blocks)
-        M = G * 42
-        conv_flops = 2.0 * M * 128 * 9 * 128                 # one trunk conv launch
+        HWc = net.H * net.W
+        fl = flops_per_position(args.blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * args.blocks)
+        M = G * HWc
+        conv_flops = 2.0 * M * 128 * 9 * 128                 # one 128->128 trunk conv launch
         roof = None
         if args.evaluator == "resnet" and tm["n_dominant"] > 0:
             avg_ms = tm["ms_dominant"] / tm["n_dominant"]
             ach = conv_flops / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=None,
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")       # per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)
+            if args.config == "connect4" and G == 4096 and os.path.exists(tf):
+                traffic = json.load(open(tf)).get("bytes_per_launch")
+            roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
                         kernel="k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM M=%d N=128 K=1152)" % M,
                         avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+        label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[args.config]
         out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
                    value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="bf16", data="synthetic",
-                   config=dict(workload=f"Connect4 6x7, {G} concurrent games/GPU, {args.sims} sims/move (MCTS.run iteration_limit), "
-                                        f"{args.blocks}-block x128 ResNet bf16, PUCT two-tree self-play, random-init weights",
+                   config=dict(workload=f"{label}, {G} concurrent games/GPU, {args.sims} sims/move (MCTS.run iteration_limit), "
+                                        f"{args.blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
                                games_per_gpu=G, sims_per_move=args.sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
                                parallelism=f"games sharded x{world}, counters all-reduced"),
                    detail=dict(positions=positions, games_finished=games, evaluator_calls=evals, simulations=sims,
@@ -144,7 +163,7 @@ def main():
                                ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
                                ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1)),
                    roofline=roof)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "connect4":
             out["cpu_baseline"] = cpu_baseline(args, net)
         print(json.dumps(out), flush=True)
     eng.close()

@@ -158,12 +158,18 @@ template <class G> struct EngineT : gaz_engine {
         E.c_visit = cfg.c_visit; E.c_scale = cfg.c_scale; E.gumbel_m = cfg.gumbel_m;
         if (gumbel && (cfg.gumbel_m < 2 || cfg.run_iterations < 1)) return fail("Gumbel search needs m >= 2 and run_iterations >= 1");
         E.node_bytes = gumbel ? gumbel_node_bytes<G>() : NodeLayout<G>::SIZE;
+        // re-root compaction: needed where a whole-game arena does not fit (Gomoku: 4.2 KB records); 0 = auto
+        E.compact = gumbel ? 0 : (cfg.compact_trees == 0 ? (G::ID == GAME_GMK ? 1 : 0) : (cfg.compact_trees > 0 ? 1 : 0));
         E.n_games = n; E.run_iterations = cfg.run_iterations; E.max_actions = cfg.max_actions;
         if (cfg.max_actions > G::MAXT || cfg.max_actions <= 0) return fail("max_actions out of range for this game");
         E.explore_first = cfg.num_explore_actions_first; E.explore_second = cfg.num_explore_actions_second;
         E.create_new_root = cfg.create_new_root; E.sync_moves = cfg.sync_moves; E.use_dirichlet = cfg.use_dirichlet;
         int npt = cfg.nodes_per_tree;
         if (npt <= 0 && gumbel) npt = 2 * (cfg.run_iterations + cfg.gumbel_m) + 3 * G::A + 64;   // fresh tree every move
+        if (npt <= 0 && E.compact) {   // per half: kept subtree + one run; generous bound, ERR_ARENA_FULL if a game exceeds it
+            const int its = cfg.run_iterations < 3 * G::A ? 3 * G::A : cfg.run_iterations;
+            npt = 4 * its + 3 * G::A + 64;
+        }
         if (npt <= 0) {   // a tree lives for the whole game and gains <= 1 record per simulation of its own moves
             const int own_moves = (cfg.max_actions + 1) / 2 + 1;
             int its = cfg.run_iterations < 3 * G::A ? 3 * G::A : cfg.run_iterations;
@@ -176,7 +182,7 @@ template <class G> struct EngineT : gaz_engine {
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
         E.key0 = (uint32_t)cfg.seed; E.key1 = (uint32_t)(cfg.seed >> 32); E.slot_offset = cfg.slot_offset;
-        const size_t arena_bytes = (size_t)n * 2 * (size_t)npt * (size_t)E.node_bytes;
+        const size_t arena_bytes = (size_t)n * 2 * (E.compact ? 2 : 1) * (size_t)npt * (size_t)E.node_bytes;
         void* a = nullptr;
         HIP_OK(hipMalloc(&a, arena_bytes));               // not zeroed: every record is written before it is read
         allocs.push_back(a); E.arena = (uint8_t*)a;

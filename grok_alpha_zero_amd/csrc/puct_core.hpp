@@ -36,7 +36,7 @@ template <class G> struct DevParams {
     int32_t create_new_root, sync_moves, nodes_per_tree, ring_cap, use_dirichlet, max_tree_sims;
     double c_init, c_base, alpha, eps;
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
-    int32_t gumbel_m, node_bytes;
+    int32_t gumbel_m, node_bytes, compact;
     float one_minus_eps;
     uint32_t key0, key1, slot_offset;
     // state in HBM
@@ -81,7 +81,8 @@ template <class T> GAZ_DEV T uni(T v) {
 }
 
 template <class G> GAZ_DEV NodeRef<G> node_at(const DevParams<G>& E, int g, int t, int idx) {
-    size_t off = (((size_t)g * 2 + t) * (size_t)E.nodes_per_tree + (size_t)idx) * (size_t)E.node_bytes;
+    const size_t half = E.compact ? (size_t)E.trees[(size_t)g * 2 + t].half : 0;   // arena = [game][tree][half][node]
+    size_t off = ((((size_t)g * 2 + t) * (E.compact ? 2 : 1) + half) * (size_t)E.nodes_per_tree + (size_t)idx) * (size_t)E.node_bytes;
     return NodeRef<G>{E.arena + off};
 }
 
@@ -473,6 +474,44 @@ template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameSt
     backup<G>(E, g, t, ts, S.path, depth, -value, 1u);                 // MCTS.py:511
 }
 
+// Re-root with compaction (the arena is double-buffered): breadth-first copy of the subtree under `root_old` into the other
+// half, relabelling child / parent indices; the discarded siblings (MCTS.py:620-655 leaves them to the garbage collector)
+// simply stay behind.  Wave-cooperative record copies; returns the new node count or -1.
+template <class G> GAZ_DEV int compact_subtree(const DevParams<G>& E, int g, int t, TreeState& ts, int root_old) {
+    const size_t oh = ts.half, nh = oh ^ 1, nb = (size_t)E.node_bytes;
+    uint8_t* base_o = E.arena + ((((size_t)g * 2 + t) * 2 + oh) * (size_t)E.nodes_per_tree) * nb;
+    uint8_t* base_n = E.arena + ((((size_t)g * 2 + t) * 2 + nh) * (size_t)E.nodes_per_tree) * nb;
+    const int words = (int)(nb / 16);
+    auto copy_rec = [&](int dst, int src) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(base_o + (size_t)src * nb);
+        uint4* d4 = reinterpret_cast<uint4*>(base_n + (size_t)dst * nb);
+        for (int i = lane_id(); i < words; i += WAVE) d4[i] = s4[i];
+    };
+    copy_rec(0, root_old);
+    wave_sync();
+    if (lane_id() == 0) reinterpret_cast<NodeHdr*>(base_n)->parent = -1;
+    int n_new = 1;
+    for (int i = 0; i < n_new; ++i) {
+        NodeRef<G> nd{base_n + (size_t)i * nb};
+        wave_sync();
+        if (uni((int)nd.hdr()->flags) & NF_TERMINAL_PARENT) continue;          // children are leaf codes, no records
+        const int nch = uni((int)nd.hdr()->n_children);
+        for (int s = 0; s < nch; ++s) {
+            const int c = uni(nd.child()[s]);
+            if (c < 0) continue;
+            if (n_new >= E.nodes_per_tree) { set_error(E.error, ERR_ARENA_FULL); return -1; }
+            copy_rec(n_new, c);
+            wave_sync();
+            if (lane_id() == 0) { nd.child()[s] = n_new; reinterpret_cast<NodeHdr*>(base_n + (size_t)n_new * nb)->parent = i; }
+            n_new++;
+        }
+    }
+    wave_sync();
+    if (lane_id() == 0) { ts.half = (uint32_t)nh; ts.root = 0; ts.n_nodes = (uint32_t)n_new; }
+    wave_sync();
+    return n_new;
+}
+
 // K11: prune_tree / _set_root for tree t after `action` was played.  Returns true if the tree must be
 // rebuilt with create_expand_root (MCTS.py:661-671).
 template <class G> GAZ_DEV bool prune(const DevParams<G>& E, int g, TreeState& ts, int t, int action) {
@@ -490,7 +529,10 @@ template <class G> GAZ_DEV bool prune(const DevParams<G>& E, int g, TreeState& t
     if (c < 0) return true;                                           // (terminal leaf: never pruned on a live game)
     const uint32_t v = uni(r.N()[found]);
     wave_sync();
-    if (lane_id() == 0) { ts.root = c; ts.root_visits = (uint64_t)v; }   // MCTS.py:654-655
+    if (E.compact) {
+        if (compact_subtree<G>(E, g, t, ts, c) < 0) return false;
+        if (lane_id() == 0) ts.root_visits = (uint64_t)v;
+    } else if (lane_id() == 0) { ts.root = c; ts.root_visits = (uint64_t)v; }   // MCTS.py:654-655
     wave_sync();
     return false;
 }

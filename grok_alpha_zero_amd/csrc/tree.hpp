@@ -59,7 +59,8 @@ struct TreeState {        // 32 bytes, one per (game, tree)
     uint32_t n_nodes;     // bump allocator
     uint64_t root_visits; // Root.visits (MCTS.py:70, carried over on re-root MCTS.py:654)
     uint32_t event;       // RNG event counter of this tree's stream
-    uint32_t pad[3];
+    uint32_t half;        // which half of the (double-buffered) arena holds the tree (re-root compaction)
+    uint32_t pad[2];
 };
 
 // per-game phases of the self-play state machine (Self_Play.play, Self_Play.py:71-157)

@@ -137,3 +137,11 @@ def test_emu_gumbel_engine_matches_reference_fixture(emu_lib, name):
     """Gumbel search (sequential halving + completed-Q selection) on the emulation build vs the reference's own output."""
     fx = np.load(os.path.join(GOLDEN, name + ".npz"))
     assert_matches_fixture(play_gumbel_fixture(fx, emu_lib), fx)
+
+
+@pytest.mark.parametrize("name", ["c4_puct_a", "c4_puct_c", "gmk_puct_a", "ttt_puct_b"])
+def test_emu_reroot_compaction_does_not_change_results(emu_lib, name):
+    """Double-buffered arena with breadth-first compaction at every re-root (default for Gomoku) vs the reference fixture."""
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert_matches_fixture(play_fixture(fx, emu_lib, compact_trees=1), fx)
+    assert_matches_fixture(play_fixture(fx, emu_lib, compact_trees=-1), fx)

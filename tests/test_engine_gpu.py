@@ -153,3 +153,16 @@ def test_hip_gumbel_matches_oracle_many_games(oracle, game, G, n, max_actions, m
         checked += 1
     assert checked == G
     eng.close()
+
+
+def test_hip_reroot_compaction_matches_oracle(oracle):
+    """Re-root compaction forced on for Connect4 (it is the default only for Gomoku): results must not change."""
+    G, iters = 128, 50
+    eng = _engine("Connect4", G, iters, 42, 8, 7, 2.5, 0.5, seed=3, hash_salt=2, ring_capacity=4 * G, compact_trees=1)
+    recs = _play_until(eng, lambda rs: len({r["slot"] for r in rs if r["game_seq"] == 0}) == G)
+    for r in recs:
+        if r["game_seq"] == 0:
+            o = oracle.selfplay_game("Connect4", iters, 42, 8, 7, 2.5, 0.5, 3, r["slot"], 0, hash_salt=2)
+            for k in ("actions", "root_N", "root_visits", "root_W", "policies"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg=k)
+    eng.close()
