@@ -124,6 +124,7 @@ def main():
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     s1 = eng.stats()
     tm = eng.timing()
+    eng_kernel = eng.dominant_kernel()
     eng.timing_reset(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
@@ -135,19 +136,19 @@ def main():
     if rank == 0:
         HWc = net.H * net.W
         fl = flops_per_position(args.blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * args.blocks)
-        M = G * HWc
-        conv_flops = 2.0 * M * 128 * 9 * 128                 # one 128->128 trunk conv launch
         roof = None
-        if args.evaluator == "resnet" and tm["n_dominant"] > 0:
+        kname, kflops = eng_kernel
+        if args.evaluator == "resnet" and tm["n_dominant"] > 0 and kflops > 0:
             avg_ms = tm["ms_dominant"] / tm["n_dominant"]
-            ach = conv_flops / (avg_ms * 1e-3) / 1e12
+            ach = kflops / (avg_ms * 1e-3) / 1e12
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")       # per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)
             if args.config == "connect4" and G == 4096 and os.path.exists(tf):
-                traffic = json.load(open(tf)).get("bytes_per_launch")
+                tj = json.load(open(tf))
+                if tj.get("kernel_tag") and tj["kernel_tag"] in kname:
+                    traffic = tj.get("bytes_per_launch")
             roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
-                        kernel="k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM M=%d N=128 K=1152)" % M,
-                        avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+                        kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
         label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[args.config]
         out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
                    value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

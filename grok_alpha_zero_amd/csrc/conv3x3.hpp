@@ -56,6 +56,7 @@ struct ConvArgs {
 };
 
 constexpr int CONV_HALO_MAX = 16;           // W + 1 <= 16
+constexpr int CONV_AROWS_256 = 256 + 2 * CONV_HALO_MAX + 1;
 // LDS bytes of one workgroup: activation image (BM + halo rows + one zero row) + two weight slices of CIN/KSPLIT channels
 template <int CIN, int BN, int BM, int KSPLIT> constexpr size_t conv_lds_bytes() {
     return (size_t)((BM + 2 * CONV_HALO_MAX + 1) * (CIN / 8) + 2 * BN * (CIN / 8) / KSPLIT) * 16;

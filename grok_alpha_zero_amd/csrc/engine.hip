@@ -115,6 +115,7 @@ struct gaz_engine {
     virtual int synchronize() = 0;
     virtual int timing_reset(int enable) = 0;
     virtual int timing_get(double*, double*, double*, int64_t*, int64_t*) = 0;
+    virtual int dominant(char*, int, double*) = 0;
 };
 
 template <class G> struct EngineT : gaz_engine {
@@ -410,6 +411,12 @@ template <class G> struct EngineT : gaz_engine {
         if (eval) eval->timing_reset();
         return 0;
     }
+    int dominant(char* name, int cap, double* flops) override {
+        double f = 0; const char* k = eval ? eval->dominant_kernel(E.n_games, &f) : "";
+        if (name && cap > 0) { strncpy(name, k, cap - 1); name[cap - 1] = 0; }
+        if (flops) *flops = f;
+        return 0;
+    }
     int timing_get(double* ms_tree, double* ms_eval, double* ms_dom, int64_t* n_dom, int64_t* n_waves) override {
         HIP_OK(hipStreamSynchronize(stream));
         double t = 0, e = 0;
@@ -463,6 +470,7 @@ int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int
 int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]) { return h->get_stats(out); }
 int gaz_engine_synchronize(gaz_engine* h) { return h->synchronize(); }
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable) { return h->timing_reset(enable); }
+int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops) { return h->dominant(name, cap, flops); }
 int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }
 
 }  // extern "C"

@@ -19,6 +19,8 @@ struct Evaluator {
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
+    // the kernel bench.py prices against the roofline: name and algorithmic FLOPs of one launch at batch n
+    virtual const char* dominant_kernel(int n, double* flops) { (void)n; *flops = 0; return ""; }
 };
 
 // synthetic evaluator for parity tests: outputs are exact float32 functions of a hash of the input row

@@ -21,6 +21,7 @@
 #include "evaluator.hpp"
 #include "conv3x3.hpp"
 #include "netops.hpp"
+#include "resblock.hpp"
 
 namespace gaz {
 
@@ -158,7 +159,8 @@ struct ResNetEvaluator : Evaluator {
     int H, W, C, A, HW, blocks, filters, nmax, logits;
     std::map<std::string, float*> f32;              // device fp32 tensors by name
     std::map<std::string, bf16_t*> b16;             // device bf16 conv weights by name
-    bf16_t *X = nullptr, *Aa = nullptr, *Hh = nullptr;
+    bf16_t *X = nullptr, *Aa = nullptr, *Hh = nullptr, *X2 = nullptr;
+    bool fused = true;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
     bool loaded = false;
@@ -237,7 +239,18 @@ struct ResNetEvaluator : Evaluator {
         hipLaunchKernelGGL(k_stem, dim3((M + 63) / 64), dim3(256), 0, s, st);
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
-        for (int i = 0; i < blocks; ++i) {
+        bf16_t* cur = X;
+        for (int i = 0; fused && i < blocks; ++i) {             // one kernel per residual block (resblock.hpp)
+            const std::string b = "block" + std::to_string(i);
+            ResBlockArgs r; r.xin = cur; r.xout = cur == X ? X2 : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
+            r.s1 = f32[b + ".bn1.scale"]; r.t1 = f32[b + ".bn1.shift"]; r.s2 = f32[b + ".conv1.scale"]; r.t2 = f32[b + ".conv1.shift"];
+            r.b2 = f32[b + ".conv2.bias"]; r.M = M; r.H = H; r.W = W;
+            const int bmo = RB_ROWS - 2 * (W + 1);
+            const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
+            hipLaunchKernelGGL(k_resblock, dim3((M + bmo - 1) / bmo), dim3(RB_THREADS), lds, s, r);
+            cur = r.xout;
+        }
+        for (int i = 0; !fused && i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i), nb = "block" + std::to_string(i + 1);
             conv_trunk(s, Aa, b16[b + ".conv1.w"], f32[b + ".conv1.scale"], f32[b + ".conv1.shift"], nullptr, Hh, ACT_RELU,
                        nullptr, nullptr, nullptr, M);
@@ -248,7 +261,7 @@ struct ResNetEvaluator : Evaluator {
         if (timing) hipEventRecord(e1, s);
         {
             ConvArgs a; memset(&a, 0, sizeof(a));
-            a.in = X; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
+            a.in = cur; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
             a.p_fs = f32["p.bn0.scale"]; a.p_ft = f32["p.bn0.shift"]; a.v_fs = f32["v.bn0.scale"]; a.v_ft = f32["v.bn0.shift"];
             a.p_feat = pfeat; a.v_feat = vfeat;
             const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
@@ -270,7 +283,13 @@ struct ResNetEvaluator : Evaluator {
     void timing_get(double* ms, int64_t* launches) override {
         double t = 0;
         for (size_t i = 0; i + 1 < tev.size(); i += 2) { float a = 0; hipEventElapsedTime(&a, tev[i], tev[i + 1]); t += a; }
-        *ms = t; *launches = (int64_t)(tev.size() / 2) * 2 * blocks;
+        *ms = t; *launches = (int64_t)(tev.size() / 2) * (fused ? 1 : 2) * blocks;
+    }
+    const char* dominant_kernel(int n, double* flops) override {
+        const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
+        *flops = fused ? 2 * conv : conv;
+        return fused ? "k_resblock (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
+                     : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
 };
 
@@ -474,11 +493,13 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->H = H; e->W = W; e->C = C; e->A = A; e->HW = H * W; e->blocks = cfg.net_blocks; e->filters = 128; e->nmax = cfg.n_games;
     e->logits = cfg.policy_is_logits;
     const size_t M = (size_t)cfg.n_games * e->HW;
+    e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
     e->pd1 = e->dalloc<float>((size_t)cfg.n_games * 128); e->vd1 = e->dalloc<float>((size_t)cfg.n_games * 128);
     if (!e->X || !e->Aa || !e->Hh || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1) { *err = "hipMalloc failed"; delete e; return nullptr; }
     // dynamic LDS above 64 KB needs the attribute
+    hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -72,11 +72,12 @@ def load_library(lib_path=None):
     L.gaz_engine_get_stats.argtypes = [H, C.POINTER(C.c_uint64)]
     L.gaz_engine_synchronize.argtypes = [H]
     L.gaz_engine_timing_reset.argtypes = [H, C.c_int32]
+    L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
-              "synchronize", "timing_reset", "timing_get"):
+              "synchronize", "timing_reset", "timing_get", "dominant_kernel"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -246,6 +247,11 @@ class SelfPlayEngine:
     # ---- measurement ----------------------------------------------------------------------------------
     def timing_reset(self, enable=True):
         self._ck(self.L.gaz_engine_timing_reset(self.h, int(enable)))
+
+    def dominant_kernel(self):
+        buf = C.create_string_buffer(256); fl = C.c_double()
+        self._ck(self.L.gaz_engine_dominant_kernel(self.h, buf, 256, C.byref(fl)))
+        return buf.value.decode(), fl.value
 
     def timing(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

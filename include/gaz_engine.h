@@ -113,6 +113,8 @@ int gaz_engine_synchronize(gaz_engine* h);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);
+/* the kernel priced against the roofline: its name (copied into `name`) and the algorithmic FLOPs of one launch */
+int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops_per_launch);
 int gaz_engine_timing_get(gaz_engine* h, double* ms_tree, double* ms_eval, double* ms_dominant, int64_t* n_dominant, int64_t* n_waves);
 
 #ifdef __cplusplus
