@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--waves-per-step", type=int, default=400)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "hash"])
+    ap.add_argument("--max-tree-sims", type=int, default=0, help="evaluation-free simulations per game per wave (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -95,7 +96,7 @@ def main():
     eng = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
                          evaluator=EVAL_RESNET if args.evaluator == "resnet" else EVAL_HASH, net_blocks=args.blocks,
                          hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
-                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel)
+                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims)
     if args.evaluator == "resnet":
         eng.load_weights(net.export_engine_weights())
 

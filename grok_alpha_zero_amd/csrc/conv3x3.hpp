@@ -52,7 +52,6 @@ struct ConvArgs {
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft;
     float* p_feat; float* v_feat;
     int M, H, W;
-    int dbg;                 // timing experiments only (GAZ_CONV_DBG): 1 = no weight DMA after tap 0, 2 = no epilogue, 4 = no MFMA
 };
 
 constexpr int CONV_HALO_MAX = 16;           // W + 1 <= 16
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
     for (int sl = 0; sl < NTAPS * KSPLIT; ++sl) {
         const int tap = NTAPS == 9 ? sl / KSPLIT : 4, ks0 = (sl % KSPLIT) * KSS;
         const uint4* Bc = Bs + (sl & 1) * BSL;
-        if (sl + 1 < NTAPS * KSPLIT && !(a.dbg & 1)) {  // DMA of the next slice into the other buffer, in flight during the MFMAs
+        if (sl + 1 < NTAPS * KSPLIT ) {  // DMA of the next slice into the other buffer, in flight during the MFMAs
             uint4* Bn = Bs + ((sl + 1) & 1) * BSL;
             const uint4* wsrc = w4 + (size_t)(sl + 1) * BSL;
             for (int base = wave * 64; base < BSL; base += CONV_THREADS)
@@ -174,14 +173,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
                 const bf16x8 af = *reinterpret_cast<bf16x8*>(&afr[cur][tm]);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    if (!(a.dbg & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<bf16x8*>(&bfr[cur][tn]), acc[tm][tn], 0, 0, 0);
             }
         }
         __syncthreads();                            // slice tap+1 landed; everyone is done reading slice tap
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (a.dbg & 2) return;
     if (EPI == 0) {
         constexpr int CT = BN + 4;
         float* Ct = reinterpret_cast<float*>(lds);  // [BM][BN + 4] fp32 over the (now idle) image + slices

@@ -178,7 +178,7 @@ template <class G> struct EngineT : gaz_engine {
         }
         E.nodes_per_tree = npt;
         E.ring_cap = cfg.ring_capacity;
-        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 32;
+        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 4;   // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);

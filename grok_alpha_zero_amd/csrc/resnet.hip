@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
             o1[j] = f2bf(v); o2[j] = f2bf(fmaxf(v * sb[j] + tb[j], 0.0f));
         }
         *reinterpret_cast<uint4*>(a.out1 + (size_t)gr * 128 + ch0) = *reinterpret_cast<uint4*>(o1);
-        *reinterpret_cast<uint4*>(a.out2 + (size_t)gr * 128 + ch0) = *reinterpret_cast<uint4*>(o2);
+        if (a.out2) *reinterpret_cast<uint4*>(a.out2 + (size_t)gr * 128 + ch0) = *reinterpret_cast<uint4*>(o2);
     }
 }
 
@@ -107,6 +107,36 @@ __global__ __launch_bounds__(128) void k_dense1(const float* feat, const float* 
 #pragma unroll
     for (int p = 0; p < 8; ++p)
         if (b0 + p < B) out[(size_t)(b0 + p) * 128 + j] = fmaxf(acc[p] * s + t, 0.0f);
+}
+
+// ---- heads: the same Dense(F -> 128) + folded BN + ReLU for BOTH heads on the matrix cores, exact fp32
+// (v_mfma_f32_32x32x2_f32): block = 32 positions x 128 outputs, 4 waves x 32 columns; blockIdx.y = head.
+struct Dense1Args { const float* feat[2]; const float* w[2]; const float* scale[2]; const float* shift[2]; float* out[2]; int B, F; };
+__global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
+    extern __shared__ float fl[];                  // [32][F + 1]
+    const int head = blockIdx.y, b0 = blockIdx.x * 32, F = a.F, FP = F + 1;
+    const float* feat = a.feat[head]; const float* w = a.w[head];
+    for (int i = threadIdx.x; i < 32 * F; i += 256) {
+        const int p = i / F, k = i % F;
+        fl[p * FP + k] = (b0 + p < a.B) ? feat[(size_t)(b0 + p) * F + k] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, n = wave * 32 + l31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < F; k += 2) {               // A[i = l31][k + lhi], B[k + lhi][j = l31]
+        const float av = fl[l31 * FP + k + lhi];
+        const float bv = w[(size_t)(k + lhi) * 128 + n];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    const float s = a.scale[head][n], t = a.shift[head][n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (b0 + row < a.B) a.out[head][(size_t)(b0 + row) * 128 + n] = fmaxf(acc[r] * s + t, 0.0f);
+    }
 }
 
 // ---- heads tail: Dense(128 -> 64) -> Dense(64 -> A | 1) -> softmax | tanh.  One wave per position.
@@ -218,7 +248,6 @@ struct ResNetEvaluator : Evaluator {
         ConvArgs a; memset(&a, 0, sizeof(a));
         a.in = in; a.wgt = w; a.scaleA = sA; a.shiftA = tA; a.res = res; a.out1 = out1; a.act1 = act1;
         a.scaleB = sB; a.shiftB = tB; a.out2 = out2; a.M = M; a.H = H; a.W = W;
-        { const char* d = getenv("GAZ_CONV_DBG"); a.dbg = d ? atoi(d) : 0; }
         static const int variant = getenv("GAZ_CONV_VARIANT") ? atoi(getenv("GAZ_CONV_VARIANT")) : 0;
         if (variant == 0) {          // 256 rows / 512 threads / whole-tap slices, one workgroup per CU
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
@@ -235,7 +264,7 @@ struct ResNetEvaluator : Evaluator {
         const int M = n * HW;
         StemArgs st; st.in = in; st.w = f32["stem.w"]; st.scale = f32["stem.scale"]; st.shift = f32["stem.shift"];
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
-        st.out1 = X; st.out2 = Aa; st.M = M; st.H = H; st.W = W;
+        st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
         hipLaunchKernelGGL(k_stem, dim3((M + 63) / 64), dim3(256), 0, s, st);
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
@@ -268,10 +297,10 @@ struct ResNetEvaluator : Evaluator {
             hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), dim3((M + 255) / 256), dim3(512), lds, s, a);
         }
         const int F = HW * 8;
-        hipLaunchKernelGGL(k_dense1, dim3((n + 7) / 8), dim3(128), (size_t)8 * F * 4, s, pfeat, f32["p.d1.w"], f32["p.d1.scale"],
-                           f32["p.d1.shift"], pd1, n, F);
-        hipLaunchKernelGGL(k_dense1, dim3((n + 7) / 8), dim3(128), (size_t)8 * F * 4, s, vfeat, f32["v.d1.w"], f32["v.d1.scale"],
-                           f32["v.d1.shift"], vd1, n, F);
+        Dense1Args d; d.B = n; d.F = F;
+        d.feat[0] = pfeat; d.w[0] = f32["p.d1.w"]; d.scale[0] = f32["p.d1.scale"]; d.shift[0] = f32["p.d1.shift"]; d.out[0] = pd1;
+        d.feat[1] = vfeat; d.w[1] = f32["v.d1.w"]; d.scale[1] = f32["v.d1.scale"]; d.shift[1] = f32["v.d1.shift"]; d.out[1] = vd1;
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((n + 31) / 32, 2), dim3(256), (size_t)32 * (F + 1) * 4, s, d);
         TailArgs t; t.p_d1 = pd1; t.v_d1 = vd1; t.p_w2 = f32["p.d2.w"]; t.p_b2 = f32["p.d2.bias"]; t.p_w3 = f32["p.d3.w"];
         t.p_b3 = f32["p.d3.bias"]; t.v_w2 = f32["v.d2.w"]; t.v_b2 = f32["v.d2.bias"]; t.v_w3 = f32["v.d3.w"]; t.v_b3 = f32["v.d3.bias"];
         t.policy = policy; t.value = value; t.B = n; t.A = A; t.logits = logits;

@@ -50,8 +50,11 @@ GAZ_DEV int block_id() { return blockIdx.x; }
 GAZ_DEV uint64_t ballot(bool p) { return __ballot(p); }
 template <class T> GAZ_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }
 template <class T> GAZ_DEV T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
-// one wave per workgroup: s_barrier is a no-op rendezvous but orders LDS traffic for the compiler
-GAZ_DEV void wave_sync() { __syncthreads(); }
+// One wave per workgroup: lanes run in lockstep and the wave's LDS / vector-memory operations are performed in program
+// order, so cross-lane hand-offs through LDS or global memory need only a WAVEFRONT-scope fence (no instruction on
+// gfx950: no s_waitcnt vmcnt(0) drain, no s_barrier) plus a scheduling barrier for the compiler.  A workgroup-scope
+// __syncthreads() here made every hand-off wait for all outstanding stores (a full HBM round trip each).
+GAZ_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 GAZ_DEV double dsqrt(double x) { return __dsqrt_rn(x); }
 GAZ_DEV int popcll(uint64_t x) { return __popcll(x); }
 GAZ_DEV int ffsll0(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }

@@ -62,7 +62,7 @@ typedef struct {
     int32_t gumbel_m;             /* train_config["m"]: actions sampled in the first stage of sequential halving */
     double c_visit, c_scale;      /* train_config["c_visit"], ["c_scale"] (MCTS_Gumbel.py:160-161) */
     int32_t compact_trees;        /* re-root compaction of the tree arena: 0 = auto (on for Gomoku), 1 = on, -1 = off */
-    int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 32);
+    int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 4);
                                        scheduling only — results do not depend on it */
 } gaz_engine_config;
 
