@@ -50,11 +50,37 @@ template <class G> GAZ_KERNEL k_reset_games(DevParams<G> E, const int32_t* slots
     gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np;
 }
 
+// put one slot at an arbitrary position (MCTS attaches to a live game object, MCTS.py:296-313): replay `n` actions on an empty
+// board, then let the state machine build the root(s) there.
+template <class G> GAZ_KERNEL k_set_position(DevParams<G> E, int g, const int32_t* actions, int n) {
+    if (block_id() != 0 || lane_id() != 0 || g < 0 || g >= E.n_games) return;
+    GameState<G>& gs = E.games[g];
+    const uint32_t seq = gs.game_seq; const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies;
+    memset(&gs, 0, sizeof(gs));
+    gs.game_seq = seq; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np; gs.host_move = -1; gs.winner = RUNNING;
+    int player = -1;
+    for (int i = 0; i < n && i < G::MAXT; ++i) {
+        const int a = actions[i];
+        gs.board[landing_cell<G>(gs.board, a)] = (int8_t)player;
+        gs.hist[i] = (uint8_t)a; player = -player;
+        E.recs[(size_t)g * RecLayout<G>::SIZE + RecLayout<G>::OFF_ACT + i] = (uint8_t)a;
+    }
+    gs.n_hist = n < G::MAXT ? n : G::MAXT; gs.next_player = player;
+    gs.roots_todo = (E.single_tree || E.gstate) ? 1 : 3; gs.phase = (E.sync_moves && E.single_tree) ? PH_IDLE : PH_ROOT; gs.pend_kind = PEND_NONE;
+    for (int t = 0; t < 2; ++t) { TreeState& ts = E.trees[(size_t)g * 2 + t]; ts.root = -1; ts.n_nodes = 0; ts.root_visits = 0; ts.event = 0; }
+}
+
+template <class G> GAZ_KERNEL k_start_search(DevParams<G> E) {      // PH_IDLE -> build the missing root(s), then MCTS.run
+    const int g = block_id();
+    if (g >= E.n_games || lane_id() != 0) return;
+    if (E.games[g].phase == PH_IDLE) E.games[g].phase = PH_ROOT;
+}
+
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
     GameState<G>& gs = E.games[g];
-    if (gs.phase == PH_WAIT_HOST) { gs.host_move = moves ? moves[g] : -1; gs.phase = PH_APPLY; }
+    if (gs.phase == PH_WAIT_HOST || (gs.phase == PH_IDLE && moves && moves[g] >= 0)) { gs.host_move = moves ? moves[g] : -1; gs.phase = PH_APPLY; }
 }
 
 // dense copies of the last MCTS.run result of every game (engine_get_root_stats)
@@ -83,7 +109,7 @@ template <class G> GAZ_KERNEL k_count(DevParams<G> E, int32_t* out) {   // out[0
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
     const GameState<G>& gs = E.games[g];
-    if (gs.phase != PH_WAIT_HOST && gs.phase != PH_HALT) atomic_add(&out[0], 1);
+    if (gs.phase != PH_WAIT_HOST && gs.phase != PH_HALT && gs.phase != PH_IDLE) atomic_add(&out[0], 1);
     if (gs.pend_kind != PEND_NONE) atomic_add(&out[1], 1);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)gs.n_evals);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 4), (unsigned long long)gs.n_sims);
@@ -116,6 +142,9 @@ struct gaz_engine {
     virtual int timing_reset(int enable) = 0;
     virtual int timing_get(double*, double*, double*, int64_t*, int64_t*) = 0;
     virtual int dominant(char*, int, double*) = 0;
+    virtual int set_position(int, const int32_t*, int) = 0;
+    virtual int set_search_params(int, int) = 0;
+    virtual int start_search() = 0;
 };
 
 template <class G> struct EngineT : gaz_engine {
@@ -177,7 +206,7 @@ template <class G> struct EngineT : gaz_engine {
             npt = own_moves * (its + 2) + 64;
         }
         E.nodes_per_tree = npt;
-        E.ring_cap = cfg.ring_capacity;
+        E.ring_cap = cfg.ring_capacity; E.single_tree = cfg.single_tree; E.tau_mode = -1;
         E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 4;   // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
@@ -201,7 +230,7 @@ template <class G> struct EngineT : gaz_engine {
         if (dalloc(&E.error, 4)) return 1;
         if (dalloc(&dN, (size_t)n * G::A) || dalloc(&dW, (size_t)n * G::A) || dalloc(&dP, (size_t)n * G::A) ||
             dalloc(&dPol, (size_t)n * G::A) || dalloc(&dRV, n) || dalloc(&dQ, n) || dalloc(&dChosen, n) ||
-            dalloc(&dPhase, n) || dalloc(&dPending, n) || dalloc(&dCount, 8) || dalloc(&dMoves, n) || dalloc(&dSlots, n)) return 1;
+            dalloc(&dPhase, n) || dalloc(&dPending, n) || dalloc(&dCount, 8) || dalloc(&dMoves, (size_t)n + G::MAXT) || dalloc(&dSlots, n)) return 1;
         std::string e2;
         eval = make_evaluator(cfg, G::H, G::W, G::C, G::A, &e2);
         if (!eval && cfg.evaluator != GAZ_EVAL_EXTERNAL) return fail("evaluator: " + e2);
@@ -411,6 +440,19 @@ template <class G> struct EngineT : gaz_engine {
         if (eval) eval->timing_reset();
         return 0;
     }
+    int set_position(int slot, const int32_t* actions, int n) override {
+        if (slot < 0 || slot >= E.n_games || n < 0 || n > G::MAXT) return fail("set_position: bad slot / history length");
+        if (n > 0) HIP_OK(hipMemcpyAsync(dMoves, actions, sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));   // dMoves holds >= MAXT? n_games ints
+        GAZ_LAUNCH(k_set_position<G>, 1, WAVE, stream, E, slot, (const int32_t*)dMoves, n);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    int start_search() override { GAZ_LAUNCH(k_start_search<G>, E.n_games, WAVE, stream, E); HIP_OK(hipGetLastError()); return 0; }
+    int set_search_params(int run_iterations, int tau_mode) override {
+        if (run_iterations > 0) E.run_iterations = run_iterations;
+        E.tau_mode = tau_mode;
+        return 0;
+    }
     int dominant(char* name, int cap, double* flops) override {
         double f = 0; const char* k = eval ? eval->dominant_kernel(E.n_games, &f) : "";
         if (name && cap > 0) { strncpy(name, k, cap - 1); name[cap - 1] = 0; }
@@ -470,6 +512,9 @@ int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int
 int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]) { return h->get_stats(out); }
 int gaz_engine_synchronize(gaz_engine* h) { return h->synchronize(); }
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable) { return h->timing_reset(enable); }
+int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions, int32_t n) { return h->set_position(slot, actions, n); }
+int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode) { return h->set_search_params(run_iterations, tau_mode); }
+int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops) { return h->dominant(name, cap, flops); }
 int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }
 

@@ -448,7 +448,7 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
             wave_sync();
             bool ended = winner != RUNNING;
             if (ply + 1 == E.max_actions) { winner = 0; ended = true; }
-            if (!ended && lane_id() == 0) { gs.roots_todo = 1; gs.phase = PH_ROOT; }
+            if (!ended && lane_id() == 0) { gs.roots_todo = 1; gs.phase = (E.sync_moves && E.single_tree) ? PH_IDLE : PH_ROOT; }
             if (ended && lane_id() == 0) {
                 gs.winner = winner;
                 int32_t* hdr = reinterpret_cast<int32_t*>(rec);

@@ -37,6 +37,8 @@ template <class G> struct DevParams {
     double c_init, c_base, alpha, eps;
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
     int32_t gumbel_m, node_bytes, compact;
+    int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
+    int32_t tau_mode;          // -1: Self_Play's exploration schedule; 0 / 1: tau fixed by the caller (MCTS.update_hyperparams)
     float one_minus_eps;
     uint32_t key0, key1, slot_offset;
     // state in HBM
@@ -639,7 +641,7 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
         if (phase == PH_NEW_GAME) {                                    // Game.__init__ + Self_Play.__init__ (Self_Play.py:37-57)
             for (int c = lane_id(); c < G::BPAD; c += WAVE) gs.board[c] = 0;
             if (lane_id() == 0) {
-                gs.n_hist = 0; gs.next_player = -1; gs.roots_todo = 3; gs.phase = PH_ROOT; gs.winner = RUNNING;
+                gs.n_hist = 0; gs.next_player = -1; gs.roots_todo = E.single_tree ? 1 : 3; gs.phase = PH_ROOT; gs.winner = RUNNING;
                 gs.host_move = -1; gs.move_evals = 0;
                 trees[0].root = -1; trees[0].event = 0; trees[0].n_nodes = 0; trees[0].root_visits = 0;
                 trees[1].root = -1; trees[1].event = 0; trees[1].n_nodes = 0; trees[1].root_visits = 0;
@@ -665,7 +667,8 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
                 const int num = gs.n_hist;
                 gs.tau_on[0] = (num % 2 == 0 && num / 2 < E.explore_first) ? 1 : 0;
                 gs.tau_on[1] = ((num + 1) % 2 == 0 && (num + 1) / 2 < E.explore_second) ? 1 : 0;
-                gs.runner = (gs.next_player == -1) ? 0 : 1;
+                if (E.tau_mode >= 0) { gs.tau_on[0] = E.tau_mode; gs.tau_on[1] = E.tau_mode; }
+                gs.runner = E.single_tree ? 0 : ((gs.next_player == -1) ? 0 : 1);
                 int lim = E.run_iterations;
                 if (len_legal == 1) lim = 1; else if (lim < len_legal) lim = len_legal * 3;
                 gs.iter_limit = lim; gs.sims_done = 0; gs.fully_visited = 0; gs.move_evals = 0;
@@ -770,11 +773,11 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
             int todo = 0;
             if (!ended) {
                 if (prune<G>(E, g, trees[0], 0, action)) todo |= 1;   // both trees prune (Self_Play.py:149-150)
-                if (prune<G>(E, g, trees[1], 1, action)) todo |= 2;
+                if (!E.single_tree && prune<G>(E, g, trees[1], 1, action)) todo |= 2;
             }
             // Self_Play.py:155-157: reaching max_actions forces winner = 0 — even when that last action won
             if (ply + 1 == E.max_actions) { winner = 0; ended = true; }
-            if (!ended && lane_id() == 0) { gs.roots_todo = todo; gs.phase = PH_ROOT; }
+            if (!ended && lane_id() == 0) { gs.roots_todo = todo; gs.phase = (E.sync_moves && E.single_tree) ? PH_IDLE : PH_ROOT; }
             if (ended) {
                 if (lane_id() == 0) {
                     gs.winner = winner;

@@ -66,7 +66,8 @@ struct TreeState {        // 32 bytes, one per (game, tree)
 // per-game phases of the self-play state machine (Self_Play.play, Self_Play.py:71-157)
 enum : int32_t {
     PH_NEW_GAME = 0, PH_ROOT = 1, PH_MOVE_BEGIN = 2, PH_SIMS = 3, PH_MOVE_END = 4, PH_WAIT_HOST = 5,
-    PH_APPLY = 6, PH_RING_WAIT = 7, PH_HALT = 8
+    PH_APPLY = 6, PH_RING_WAIT = 7, PH_HALT = 8,
+    PH_IDLE = 9            // sync + single-tree hosts (mcts.py): position set / move applied, waiting for run() or the next move
 };
 enum : int32_t { PEND_NONE = 0, PEND_ROOT = 1, PEND_EXPAND = 2 };
 

@@ -16,7 +16,7 @@ GAME_IDS = {"TicTacToe": 0, "Connect4": 1, "Gomoku": 2}
 GAME_DIMS = {0: (3, 3, 2, 9), 1: (6, 7, 4, 7), 2: (15, 15, 2, 225)}  # H, W, C, A
 SEARCH_PUCT, SEARCH_GUMBEL = 0, 1
 EVAL_HASH, EVAL_RESNET, EVAL_EXTERNAL = 0, 1, 2
-PH_WAIT_HOST, PH_HALT = 5, 8
+PH_WAIT_HOST, PH_HALT, PH_IDLE = 5, 8, 9
 
 
 class EngineConfig(C.Structure):
@@ -28,7 +28,7 @@ class EngineConfig(C.Structure):
                 ("seed", C.c_uint64), ("slot_offset", C.c_uint32), ("evaluator", C.c_int32), ("hash_salt", C.c_uint32),
                 ("device", C.c_int32), ("net_blocks", C.c_int32), ("net_filters", C.c_int32), ("policy_is_logits", C.c_int32),
                 ("gumbel_m", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double), ("compact_trees", C.c_int32),
-                ("max_tree_sims_per_wave", C.c_int32)]
+                ("single_tree", C.c_int32), ("max_tree_sims_per_wave", C.c_int32)]
 
 
 class Tensor(C.Structure):
@@ -72,12 +72,15 @@ def load_library(lib_path=None):
     L.gaz_engine_get_stats.argtypes = [H, C.POINTER(C.c_uint64)]
     L.gaz_engine_synchronize.argtypes = [H]
     L.gaz_engine_timing_reset.argtypes = [H, C.c_int32]
+    L.gaz_engine_set_position.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    L.gaz_engine_set_search_params.argtypes = [H, C.c_int32, C.c_int32]
+    L.gaz_engine_start_search.argtypes = [H]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
-              "synchronize", "timing_reset", "timing_get", "dominant_kernel"):
+              "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -96,7 +99,7 @@ class SelfPlayEngine:
                  create_new_root=False, sync_moves=False, nodes_per_tree=0, ring_capacity=None, slot_offset=0,
                  evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
                  policy_is_logits=False, max_tree_sims_per_wave=0, gumbel_m=0, c_visit=50.0, c_scale=1.0,
-                 compact_trees=0, lib_path=None):
+                 compact_trees=0, single_tree=False, lib_path=None):
         self.L = load_library(lib_path)
         self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
         self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
@@ -107,7 +110,7 @@ class SelfPlayEngine:
                                 num_explore_actions_second, c_puct_init, c_puct_base, dirichlet_alpha, dirichlet_epsilon,
                                 int(use_dirichlet), int(create_new_root), int(sync_moves), nodes_per_tree, ring_capacity,
                                 seed, slot_offset, evaluator, hash_salt, device, net_blocks, net_filters, int(policy_is_logits),
-                                gumbel_m, c_visit, c_scale, compact_trees, max_tree_sims_per_wave)
+                                gumbel_m, c_visit, c_scale, compact_trees, int(single_tree), max_tree_sims_per_wave)
         self.h = C.c_void_p()
         if self.L.gaz_engine_create(C.byref(self.cfg), C.byref(self.h)):
             raise EngineError(self.L.gaz_engine_last_error(None).decode())
@@ -168,6 +171,16 @@ class SelfPlayEngine:
         else:
             m = np.ascontiguousarray(moves, np.int32)
             self._ck(self.L.gaz_engine_apply_moves(self.h, m.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def set_position(self, slot, action_indices):
+        a = np.ascontiguousarray(action_indices, np.int32)
+        self._ck(self.L.gaz_engine_set_position(self.h, int(slot), a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+
+    def start_search(self):
+        self._ck(self.L.gaz_engine_start_search(self.h))
+
+    def set_search_params(self, run_iterations=0, tau_mode=-1):
+        self._ck(self.L.gaz_engine_set_search_params(self.h, int(run_iterations), int(tau_mode)))
 
     def reset_games(self, slots=None):
         if slots is None:

@@ -20,6 +20,8 @@
  *   gaz_engine_wave_begin/end  session.run(["policy","value"], {"inputs": x})  MCTS.py:224-235, Client_Server.py:28-55,162-217
  *   gaz_engine_drain_finished  the per-game arrays play() hands to HDF5        Self_Play.py:159-175
  *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
+ *   gaz_engine_set_position    MCTS.__init__ attaching to a live game object   MCTS.py:100,132,296-313
+ *   gaz_engine_set_search_params  run(iteration_limit) / update_hyperparams(tau) MCTS.py:134-168,528
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  */
 #ifndef GAZ_ENGINE_H
@@ -62,6 +64,7 @@ typedef struct {
     int32_t gumbel_m;             /* train_config["m"]: actions sampled in the first stage of sequential halving */
     double c_visit, c_scale;      /* train_config["c_visit"], ["c_scale"] (MCTS_Gumbel.py:160-161) */
     int32_t compact_trees;        /* re-root compaction of the tree arena: 0 = auto (on for Gomoku), 1 = on, -1 = off */
+    int32_t single_tree;          /* 1: one tree plays both sides (MCTS used on its own: Connect4/play.py, Game_Tester.py:480-513) */
     int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 4);
                                        scheduling only — results do not depend on it */
 } gaz_engine_config;
@@ -101,6 +104,14 @@ int gaz_engine_wave_end(gaz_engine* h);
 int gaz_engine_batch_ptrs(gaz_engine* h, void** d_inputs_i8, void** d_policy_f32, void** d_value_f32);   /* device pointers */
 int gaz_engine_read_batch(gaz_engine* h, int8_t* inputs, int32_t* pending);    /* host copies: [n_games][H*W*C], [n_games] */
 int gaz_engine_write_outputs(gaz_engine* h, const float* policy, const float* value);   /* host -> device rows */
+
+/* place one slot at the position reached by `n` actions from the empty board (new roots are built there) */
+int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions, int32_t n);
+/* iteration_limit of the following MCTS.run calls (<= 0: unchanged); tau_mode -1 = Self_Play schedule, 0 / 1 = fixed tau */
+int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode);
+
+/* sync + single_tree engines idle after set_position / apply_moves; this starts MCTS.run for the idle slots */
+int gaz_engine_start_search(gaz_engine* h);
 
 /* run the built-in evaluator on a host batch: inputs int8 [n][H*W*C] -> policy f32 [n][A], value f32 [n]; n <= n_games */
 int gaz_engine_evaluate(gaz_engine* h, const int8_t* inputs, int32_t n, float* policy, float* value, int32_t repeats, double* ms_per_batch);

@@ -166,3 +166,26 @@ def test_hip_reroot_compaction_matches_oracle(oracle):
             for k in ("actions", "root_N", "root_visits", "root_W", "policies"):
                 np.testing.assert_array_equal(r[k], o[k], err_msg=k)
     eng.close()
+
+
+def test_hip_mcts_class_matches_reference_class(oracle):
+    """grok_alpha_zero_amd.mcts.MCTS on the GPU vs the fixture recorded from the reference's MCTS class (single tree)."""
+    from grok_alpha_zero_amd.games import GAMES
+    from grok_alpha_zero_amd.mcts import MCTS
+    fx = np.load(os.path.join(GOLDEN, "c4_mcts_single.npz"))
+    game = GAMES["Connect4"]()
+    mcts = MCTS(game, None, c_puct_init=float(fx["c_puct_init"]), dirichlet_alpha=float(fx["dirichlet_alpha"]), tau=1.0,
+                seed=int(fx["seed"]), hash_salt=int(fx["salt"]))
+    for ply in range(len(fx["actions"])):
+        mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
+        move, rows = mcts.run(iteration_limit=int(fx["iteration_limit"]), use_bar=False)
+        N = np.zeros(7, np.uint32)
+        for r in rows:
+            N[int(r[0])] = r[4]
+        assert int(move) == fx["actions"][ply]
+        np.testing.assert_array_equal(N, fx["root_N"][ply])
+        game.do_action(move)
+        if game.check_win() != -2:
+            break
+        mcts.prune_tree(move)
+    mcts.close()

@@ -1,0 +1,79 @@
+"""CPU suite: the drop-in search classes (grok_alpha_zero_amd/mcts.py: MCTS, MCTS_Gumbel with the reference's constructor /
+run / prune_tree surface) on the emulation build, against fixtures recorded by driving the REFERENCE's classes the same way
+(single tree playing both sides, tools/gen_golden.py: ref_single_tree_puct) and against the Self_Play Gumbel fixtures."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from grok_alpha_zero_amd.games import GAMES
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU = os.path.join(EMU_DIR, "libgaz_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return EMU
+
+
+class _HashSession:
+    def __init__(self, oracle, A, salt):
+        self.o, self.A, self.salt, self.calls = oracle, A, salt, 0
+
+    def run(self, output_names, input_feed, **kw):
+        self.calls += 1
+        pol, val = self.o.hash_eval(input_feed["inputs"][0].astype(np.int8), self.A, self.salt)
+        return [pol.reshape(1, -1), np.array([[val]], np.float32)]
+
+
+@pytest.mark.parametrize("name", ["c4_mcts_single", "ttt_mcts_single"])
+@pytest.mark.parametrize("with_session", [True, False], ids=["session", "builtin"])
+def test_mcts_class_matches_reference_class(emu_lib, oracle, name, with_session):
+    from grok_alpha_zero_amd.mcts import MCTS
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    game = GAMES[str(fx["game"])]()
+    A = game.policy_shape[0]
+    sess = _HashSession(oracle, A, int(fx["salt"])) if with_session else None
+    mcts = MCTS(game, sess, c_puct_init=float(fx["c_puct_init"]), use_dirichlet=True, dirichlet_alpha=float(fx["dirichlet_alpha"]),
+                dirichlet_epsilon=0.25, tau=1.0, seed=int(fx["seed"]), hash_salt=int(fx["salt"]), lib_path=emu_lib)
+    for ply in range(len(fx["actions"])):
+        mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
+        move, rows = mcts.run(iteration_limit=int(fx["iteration_limit"]), use_bar=False)
+        N = np.zeros(A, np.uint32); Wv = np.zeros(A, np.float32)
+        for r in rows:
+            a = type(game).action_to_index(r[0]); N[a] = r[4]; Wv[a] = r[3]
+        assert type(game).action_to_index(move) == fx["actions"][ply]
+        np.testing.assert_array_equal(N, fx["root_N"][ply])
+        np.testing.assert_array_equal(Wv, fx["root_W"][ply])
+        assert rows[0][6] == fx["root_visits"][ply] and rows == sorted(rows, key=lambda r: r[4], reverse=True)
+        game.do_action(move)
+        if game.check_win() != -2:
+            break
+        mcts.prune_tree(move)
+    assert ply == len(fx["actions"]) - 1
+    if with_session:
+        assert sess.calls == int(fx["evaluator_calls"])
+    mcts.close()
+
+
+def test_mcts_gumbel_class_plays_the_self_play_fixture(emu_lib, oracle):
+    from grok_alpha_zero_amd.mcts import MCTS_Gumbel
+    fx = np.load(os.path.join(GOLDEN, "c4_gumbel_a.npz"))
+    game = GAMES["Connect4"]()
+    sess = _HashSession(oracle, 7, int(fx["salt"]))
+    mcts = MCTS_Gumbel(game, sess, use_gumbel_noise=True, m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]),
+                       seed=int(fx["seed"]), lib_path=emu_lib)
+    for ply in range(12):
+        move, rows = mcts.run(iteration_limit=int(fx["run_iterations"]), use_bar=False)
+        assert int(move) == fx["actions"][ply]
+        pol = np.zeros(7, np.float32)
+        for r in rows:
+            pol[int(r[0])] = r[1]
+        np.testing.assert_array_equal(pol, fx["policies"][ply])
+        game.do_action(move)
+        mcts.prune_tree(move)
+    mcts.close()

@@ -95,6 +95,34 @@ PUCT_CASES = [
 ]
 
 
+def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, max_plies):
+    """The reference's MCTS class used on its own (Connect4/play.py, Game_Tester.py:480-513): ONE tree searches every move."""
+    ref = ref_shim.load_reference()
+    inj = ref_shim.activate(seed, 0, 0)
+    cls = getattr(ref[GAME_CLASS[game][0]], GAME_CLASS[game][1])
+    g = cls(); A = g.policy_shape[0]
+    sess = ref_shim.HashSession(A, salt)
+    mcts = ref["MCTS"].MCTS(g, sess, use_njit=False, c_puct_init=c_puct_init, use_dirichlet=True, dirichlet_alpha=alpha,
+                            dirichlet_epsilon=0.25, tau=1.0)
+    acts, rN, rW, rP, rV = [], [], [], [], []
+    for ply in range(max_plies):
+        mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
+        move, rows = mcts.run(iteration_limit=iteration_limit, use_bar=False)
+        N = np.zeros(A, np.uint32); Wv = np.zeros(A, np.float32); P = np.zeros(A, np.float32)
+        for r in rows:
+            a = action_to_index(game, r[0]); N[a] = r[4]; Wv[a] = r[3]; P[a] = r[5]
+        acts.append(action_to_index(game, move)); rN.append(N); rW.append(Wv); rP.append(P); rV.append(int(rows[0][6]))
+        g.do_action(move)
+        if g.check_win() != -2:
+            break
+        mcts.prune_tree(move)
+    return dict(game=game, iteration_limit=iteration_limit, c_puct_init=c_puct_init, dirichlet_alpha=alpha, seed=seed, salt=salt,
+                actions=np.array(acts, np.int32), root_N=np.array(rN), root_W=np.array(rW), root_P=np.array(rP),
+                root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls)
+
+
+SINGLE_CASES = [("c4_mcts_single", "Connect4", 60, 2.5, 0.5, 21, 9, 42), ("ttt_mcts_single", "TicTacToe", 30, 1.25, 1.0, 22, 4, 9)]
+
 GUMBEL_CASES = [
     # name, game, MCTS_iteration_limit, max_actions, m, c_visit, c_scale, seed, slot, seq, salt
     ("ttt_gumbel_a", "TicTacToe", 16, 9, 4, 50.0, 2.0, 1234, 0, 0, 7),
@@ -108,6 +136,12 @@ GUMBEL_CASES = [
 def main():
     os.makedirs(GOLD, exist_ok=True)
     only = set(sys.argv[1:])
+    for name, *cfg in SINGLE_CASES:
+        if only and name not in only:
+            continue
+        fx = ref_single_tree_puct(*cfg)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "evals", fx["evaluator_calls"], flush=True)
     for name, game, it, max_actions, m, c_visit, c_scale, seed, slot, seq, salt in GUMBEL_CASES:
         if only and name not in only:
             continue
