@@ -207,6 +207,12 @@ template <class G> struct EngineT : gaz_engine {
         }
         E.nodes_per_tree = npt;
         E.ring_cap = cfg.ring_capacity; E.single_tree = cfg.single_tree; E.tau_mode = -1;
+        if (cfg.n_opening < 0 || cfg.n_opening > 8) return fail("at most 8 opening_actions");
+        E.n_opening = cfg.n_opening;
+        for (int i = 0; i < cfg.n_opening; ++i) {
+            if (cfg.opening_actions[i] < 0 || cfg.opening_actions[i] >= G::A) return fail("opening action out of range");
+            E.opening_actions[i] = cfg.opening_actions[i]; E.opening_weights[i] = cfg.opening_weights[i];
+        }
         E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 4;   // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)

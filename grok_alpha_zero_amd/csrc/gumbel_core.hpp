@@ -430,7 +430,8 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
             wave_sync();
             if (E.sync_moves) return;
         } else if (phase == PH_APPLY) {                                        // Self_Play.py:142-157, new tree every move (:151-153)
-            const int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            if (uni(gs.n_hist) == 0 && uni(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
             const int mover = uni(gs.next_player);
             copy_board<G>(S.board, gs.board);
             wave_sync();

@@ -39,6 +39,8 @@ template <class G> struct DevParams {
     int32_t gumbel_m, node_bytes, compact;
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
     int32_t tau_mode;          // -1: Self_Play's exploration schedule; 0 / 1: tau fixed by the caller (MCTS.update_hyperparams)
+    int32_t n_opening, opening_actions[8];   // train_config["opening_actions"] (Self_Play.py:130-140)
+    double opening_weights[8];
     float one_minus_eps;
     uint32_t key0, key1, slot_offset;
     // state in HBM
@@ -592,6 +594,22 @@ template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState
     wave_sync();
 }
 
+// Self_Play.py:130-140: at move 0 the played action is drawn from opening_actions (+ the search's own move with the
+// remaining probability) through np.random.choice on the game-level stream (tree 2, event 0).
+template <class G> GAZ_DEV int opening_override(const DevParams<G>& E, int g, const GameState<G>& gs, int mcts_action) {
+    if (E.n_opening <= 0) return mcts_action;
+    int acts[9]; double w[9]; int n = E.n_opening; double sum = 0.0;
+    for (int i = 0; i < n; ++i) { acts[i] = E.opening_actions[i]; w[i] = E.opening_weights[i]; sum = sum + w[i]; }
+    if (sum < 1.0) { acts[n] = mcts_action; w[n] = 1.0 - sum; n++; }
+    det::Event e; e.key0 = E.key0; e.key1 = E.key1; e.slot = E.slot_offset + (uint32_t)g; e.game_seq = gs.game_seq;
+    e.event = 0; e.tree = 2; e.purpose = det::P_OPENING;
+    const double u = det::uniform(e);
+    double cdf[9], acc = 0.0;
+    for (int i = 0; i < n; ++i) { acc = acc + w[i]; cdf[i] = acc; }
+    for (int i = 0; i < n; ++i) if (cdf[i] / cdf[n - 1] > u) return acts[i];
+    return acts[n - 1];
+}
+
 // Finished game -> host ring (or dropped when no ring is configured), then restart / halt the slot.  false = ring full.
 template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameState<G>& gs) {
     using RL = RecLayout<G>;
@@ -751,7 +769,8 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
             wave_sync();
             if (E.sync_moves) return;
         } else if (phase == PH_APPLY) {                                // Self_Play.py:142-157
-            const int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
+            if (uni(gs.n_hist) == 0 && uni(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
             const int mover = uni(gs.next_player);
             copy_board<G>(S.board, gs.board);
             wave_sync();

@@ -134,6 +134,8 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                          search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=train_config.get("m", 0),
                          c_visit=train_config.get("c_visit", 50.0), c_scale=train_config.get("c_scale", 1.0),
                          policy_is_logits=gumbel,
+                         opening_actions=[(game_class.action_to_index(a) if hasattr(game_class, "action_to_index") else int(a), w)
+                                          for a, w in train_config.get("opening_actions", []) or []],
                          create_new_root=train_config.get("create_new_root", False), slot_offset=slot_offset, device=device,
                          evaluator=EVAL_RESNET if use_net else EVAL_HASH, hash_salt=hash_salt,
                          net_blocks=build_config.get("num_resnet_layers", 0) if use_net else 0,

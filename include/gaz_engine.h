@@ -65,6 +65,9 @@ typedef struct {
     double c_visit, c_scale;      /* train_config["c_visit"], ["c_scale"] (MCTS_Gumbel.py:160-161) */
     int32_t compact_trees;        /* re-root compaction of the tree arena: 0 = auto (on for Gomoku), 1 = on, -1 = off */
     int32_t single_tree;          /* 1: one tree plays both sides (MCTS used on its own: Connect4/play.py, Game_Tester.py:480-513) */
+    int32_t n_opening;            /* train_config["opening_actions"] (Self_Play.py:130-140): up to 8 [action, weight] pairs */
+    int32_t opening_actions[8];
+    double opening_weights[8];
     int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 4);
                                        scheduling only — results do not depend on it */
 } gaz_engine_config;

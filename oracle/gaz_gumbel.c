@@ -324,7 +324,9 @@ int gaz_selfplay_game_gumbel(const gaz_sp_config* cfg, int m, double c_visit, do
             if (rows[i].action == action) q = (float)rows[i].winrate;
         }
         rec->root_visits[T] = t.root_visits; rec->evals[T] = (uint32_t)(t.n_evals - ev0) + 0;
-        rec->q[T] = q; rec->z[T] = (float)next_player; rec->actions[T] = action; T++;
+        rec->q[T] = q; rec->z[T] = (float)next_player;
+        if (n_history == 0) action = gaz_opening_override(cfg, action, seed, slot, game_seq);
+        rec->actions[T] = action; T++;
         gaz_do_action(&g, board, action, next_player); history[n_history++] = action; next_player = -next_player;
         winner = gaz_check_win(&g, board, -next_player, action);
         if (winner == GAZ_RUNNING) { gnode_free(t.root); t.root = NULL; t.m = m; g_create_root(&t); }   /* new MCTS_Gumbel (:152-153) */

@@ -28,7 +28,7 @@ class SPConfig(C.Structure):
     _fields_ = [("game_id", C.c_int), ("run_iterations", C.c_int), ("max_actions", C.c_int),
                 ("num_explore_actions_first", C.c_int), ("num_explore_actions_second", C.c_int),
                 ("c_puct_init", C.c_double), ("c_puct_base", C.c_double), ("dirichlet_alpha", C.c_double),
-                ("create_new_root", C.c_int)]
+                ("create_new_root", C.c_int), ("n_opening", C.c_int), ("opening_actions", C.c_int * 8), ("opening_weights", C.c_double * 8)]
 
 
 class SPRecord(C.Structure):
@@ -157,15 +157,15 @@ def hash_eval(state_i8, A, salt):
 
 # ---------------------------------------------------------------- self-play of one game
 def selfplay_game_gumbel(game, iteration_limit, max_actions, m, c_visit, c_scale, seed, slot=0, game_seq=0, evaluator=None,
-                         hash_salt=0, use_libm=False):
+                         hash_salt=0, use_libm=False, opening_actions=None):
     """One Gumbel self-play game (MCTS_Gumbel.run(iteration_limit) per move, gumbel noise on, softmax policy head)."""
     return selfplay_game(game, iteration_limit, max_actions, 0, 0, 0.0, 0.0, seed, slot, game_seq, evaluator, hash_salt,
-                         use_libm=use_libm, gumbel=(m, c_visit, c_scale))
+                         use_libm=use_libm, gumbel=(m, c_visit, c_scale), opening_actions=opening_actions)
 
 
 def selfplay_game(game, run_iterations, max_actions, explore_first, explore_second, c_puct_init, dirichlet_alpha,
                   seed, slot=0, game_seq=0, evaluator=None, hash_salt=0, c_puct_base=19652.0, create_new_root=False,
-                  use_libm=False, gumbel=None):
+                  use_libm=False, gumbel=None, opening_actions=None):
     """Play one PUCT self-play game with the oracle.  evaluator(state_i8[H,W,C]) -> (policy f32[A], value f32),
     or None for the built-in hash evaluator.  Returns a dict of numpy arrays (see gaz_sp_record)."""
     L = lib()
@@ -184,6 +184,8 @@ def selfplay_game(game, run_iterations, max_actions, explore_first, explore_seco
     rec.root_visits = _p(arrs["root_visits"], C.c_uint64); rec.evals = _p(arrs["evals"], C.c_uint32)
     cfg = SPConfig(gid, run_iterations, max_actions, explore_first, explore_second, c_puct_init, c_puct_base,
                    dirichlet_alpha, int(create_new_root))
+    for i, (a, w) in enumerate(opening_actions or []):     # [(action index, weight)], train_config["opening_actions"]
+        cfg.opening_actions[i] = int(a); cfg.opening_weights[i] = float(w); cfg.n_opening = i + 1
     L.gaz_oracle_set_libm(int(use_libm))
 
     def play(fn, ctxp):

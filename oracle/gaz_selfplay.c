@@ -30,6 +30,21 @@ void gaz_hash_eval(void* ctx, const int8_t* state, int n_state, float* policy, f
     *value = (float)(hv >> 8) * (1.0f / 8388608.0f) - 1.0f;
 }
 
+/* Self_Play.py:130-140: at move 0, with opening_actions configured, the played action is drawn from
+ * opening_actions (+ the search's own action with the remaining probability) by np.random.choice (game-level stream). */
+int gaz_opening_override(const gaz_sp_config* cfg, int mcts_action, uint64_t seed, uint32_t slot, uint32_t game_seq) {
+    if (cfg->n_opening <= 0) return mcts_action;
+    int acts[9]; double w[9]; int n = cfg->n_opening; double sum = 0.0;
+    for (int i = 0; i < n; ++i) { acts[i] = cfg->opening_actions[i]; w[i] = cfg->opening_weights[i]; sum = sum + w[i]; }
+    if (sum < 1.0) { acts[n] = mcts_action; w[n] = 1.0 - sum; n++; }
+    gaz_event e; e.key[0] = (uint32_t)seed; e.key[1] = (uint32_t)(seed >> 32); e.slot = slot; e.game_seq = game_seq;
+    e.event = 0; e.tree = 2; e.purpose = GAZ_P_OPENING;
+    double u = gaz_uniform(&e), cdf[9], acc = 0.0;
+    for (int i = 0; i < n; ++i) { acc = acc + w[i]; cdf[i] = acc; }
+    for (int i = 0; i < n; ++i) if (cdf[i] / cdf[n - 1] > u) return acts[i];
+    return acts[n - 1];
+}
+
 /* Self_Play.play (Self_Play.py:71-175), use_gumbel = False. */
 int gaz_selfplay_game(const gaz_sp_config* cfg, gaz_eval_fn eval, void* ctx, uint64_t seed, uint32_t slot,
                       uint32_t game_seq, gaz_sp_record* rec) {
@@ -66,7 +81,9 @@ int gaz_selfplay_game(const gaz_sp_config* cfg, gaz_eval_fn eval, void* ctx, uin
         }
         rec->root_visits[T] = rows[0].root_visits;
         rec->evals[T] = (uint32_t)(runner->n_evals - ev0);
-        rec->q[T] = q; rec->z[T] = (float)next_player; rec->actions[T] = action;    /* :127 */
+        rec->q[T] = q; rec->z[T] = (float)next_player;                              /* :127 */
+        if (n_history == 0) action = gaz_opening_override(cfg, action, seed, slot, game_seq);                       /* :130-140 */
+        rec->actions[T] = action;                                                    /* the action PLAYED */
         T++;
         gaz_do_action(&g, board, action, next_player); history[n_history++] = action; next_player = -next_player;  /* :142 */
         winner = gaz_check_win(&g, board, -next_player, action);

@@ -18,7 +18,12 @@ typedef struct {
     int num_explore_actions_first, num_explore_actions_second;
     double c_puct_init, c_puct_base, dirichlet_alpha;
     int create_new_root;
+    int n_opening;                /* train_config["opening_actions"] (Self_Play.py:130-140): [action, weight] pairs for move 0 */
+    int opening_actions[8]; double opening_weights[8];
 } gaz_sp_config;
+
+/* the override of move 0: returns the action to play given the search's own choice */
+int gaz_opening_override(const gaz_sp_config* cfg, int mcts_action, uint64_t seed, uint32_t slot, uint32_t game_seq);
 
 /* caller-allocated record of one game, cap_T plies */
 typedef struct {

@@ -12,7 +12,7 @@ from conftest import GOLDEN, ROOT
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU = os.path.join(EMU_DIR, "libgaz_emu.so")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")) if "_open" not in p)
 
 
 @pytest.fixture(scope="module")
@@ -145,3 +145,13 @@ def test_emu_reroot_compaction_does_not_change_results(emu_lib, name):
     fx = np.load(os.path.join(GOLDEN, name + ".npz"))
     assert_matches_fixture(play_fixture(fx, emu_lib, compact_trees=1), fx)
     assert_matches_fixture(play_fixture(fx, emu_lib, compact_trees=-1), fx)
+
+
+OPENING_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_open*.npz")))
+
+
+@pytest.mark.parametrize("name", OPENING_CASES)
+def test_emu_opening_actions_match_reference(emu_lib, name):
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    r = play_fixture(fx, emu_lib, opening_actions=list(zip(fx["opening_idx"].tolist(), fx["opening_w"].tolist())))
+    assert_matches_fixture(r, fx)

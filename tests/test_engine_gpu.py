@@ -11,7 +11,7 @@ import pytest
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")) if "_open" not in p)
 
 
 def _engine(*a, **k):
@@ -189,3 +189,16 @@ def test_hip_mcts_class_matches_reference_class(oracle):
             break
         mcts.prune_tree(move)
     mcts.close()
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_open*.npz"))))
+def test_hip_opening_actions_match_reference(name):
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = _engine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), int(fx["explore_first"]),
+                  int(fx["explore_second"]), float(fx["c_puct_init"]), float(fx["dirichlet_alpha"]), int(fx["seed"]),
+                  slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8,
+                  opening_actions=list(zip(fx["opening_idx"].tolist(), fx["opening_w"].tolist())))
+    r = _play_until(eng, lambda rs: len(rs) >= 1)[0]
+    for k in ("actions", "root_N", "root_visits", "root_W", "policies"):
+        np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
+    eng.close()

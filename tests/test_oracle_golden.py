@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLDEN
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")) if "_open" not in p)
 
 
 def _run(oracle, fx, use_libm):
@@ -63,3 +63,25 @@ def test_gumbel_selfplay_matches_reference(oracle, name, use_libm):
 
 def test_gumbel_fixture_inventory():
     assert {"ttt_gumbel_a", "c4_gumbel_a", "gmk_gumbel_a"} <= set(GUMBEL_CASES)
+
+
+OPENING_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_open*.npz")))
+
+
+@pytest.mark.parametrize("name", OPENING_CASES)
+def test_opening_actions_match_reference(oracle, name):
+    """train_config["opening_actions"]: move 0 is drawn from the configured openings (Self_Play.py:130-140)."""
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    opening = list(zip(fx["opening_idx"].tolist(), fx["opening_w"].tolist()))
+    r = oracle.selfplay_game(str(fx["game"]), int(fx["run_iterations"]), int(fx["max_actions"]), int(fx["explore_first"]),
+                             int(fx["explore_second"]), float(fx["c_puct_init"]), float(fx["dirichlet_alpha"]), int(fx["seed"]),
+                             int(fx["slot"]), int(fx["game_seq"]), hash_salt=int(fx["salt"]), opening_actions=opening)
+    for k in ("actions", "root_N", "root_visits", "root_W", "states", "policies"):
+        np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
+    np.testing.assert_array_equal(r["values"], fx["values"].reshape(-1))
+
+
+def test_opening_fixtures_exercise_the_override():
+    assert len(OPENING_CASES) >= 3
+    differs = [bool(np.load(os.path.join(GOLDEN, n + ".npz"))["actions"][0] != np.load(os.path.join(GOLDEN, n + ".npz"))["search_actions"][0]) for n in OPENING_CASES]
+    assert any(differs)        # at least one fixture actually overrode the search's move

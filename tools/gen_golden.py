@@ -29,7 +29,7 @@ def action_to_index(game, action):
 
 
 def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore_second, c_puct_init, alpha,
-                      seed, slot, game_seq, salt, session=None, gumbel=None):
+                      seed, slot, game_seq, salt, session=None, gumbel=None, opening=None):
     """Run the reference's Self_Play.play() once; returns the fixture dict."""
     ref = ref_shim.load_reference()
     inj = ref_shim.activate(seed, slot, game_seq)
@@ -43,6 +43,8 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
                     "num_explore_actions_second": explore_second}
     if gumbel is not None:
         train_config.update(use_gumbel=True, m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2])
+    if opening is not None:
+        train_config["opening_actions"] = opening
     build_config = {}
     folder = f"/fake/{game}_{iteration_limit}_{seed}_{slot}_{game_seq}/1"
     ref_shim._FakeH5File.STORE.pop(folder + "/Self_Play_Data.h5", None)
@@ -68,14 +70,18 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
             a = action_to_index(game, r[0])
             rN[t, a] = r[4]; rW[t, a] = r[3]; rP[t, a] = r[5]
         rV[t] = int(rows[0][6])
+    search_acts = acts.copy()
+    acts = np.array([action_to_index(game, a) for a in g.action_history], np.int32)    # what was PLAYED (differs at move 0 with opening_actions)
     d = f.d
     n_aug = (len(d) - 1) // 3
     out = dict(game=game, iteration_limit=iteration_limit, run_iterations=int(iteration_limit * 1.5),
                max_actions=max_actions, explore_first=explore_first, explore_second=explore_second,
                c_puct_init=c_puct_init, dirichlet_alpha=alpha, seed=seed, slot=slot, game_seq=game_seq, salt=salt,
-               actions=acts, root_N=rN, root_W=rW, root_P=rP, root_visits=rV,
+               actions=acts, search_actions=search_acts, root_N=rN, root_W=rW, root_P=rP, root_visits=rV,
                states=d["boards_0"].data, policies=d["policies_0"].data, values=d["values_0"].data,
                game_stats=d["game_stats"].data, n_aug=n_aug, evaluator_calls=sess.calls)
+    if opening is not None:
+        out.update(opening_idx=np.array([action_to_index(game, a) for a, _ in opening], np.int32), opening_w=np.array([w for _, w in opening]))
     if gumbel is not None:
         out.update(m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2], run_iterations=iteration_limit)
     for k in range(n_aug):
@@ -133,9 +139,23 @@ GUMBEL_CASES = [
 ]
 
 
+OPENING_CASES = [   # name, game, limit, max_actions, ef, es, c_puct, alpha, seed, slot, seq, salt, opening_actions
+    ("gmk_puct_open", "Gomoku", 30, 6, 6, 4, 4.5, 0.05, 77, 4, 0, 5, [[[7, 7], 0.333]]),           # Gomoku/Gomoku.py:49-50
+    ("c4_puct_open_a", "Connect4", 30, 42, 8, 7, 2.5, 0.5, 78, 0, 0, 6, [[3, 0.5], [2, 0.2]]),
+    ("c4_puct_open_b", "Connect4", 30, 42, 8, 7, 2.5, 0.5, 78, 1, 0, 6, [[3, 0.5], [2, 0.2]]),
+    ("c4_puct_open_c", "Connect4", 30, 42, 8, 7, 2.5, 0.5, 78, 2, 0, 6, [[3, 0.5], [2, 0.2]]),
+]
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     only = set(sys.argv[1:])
+    for name, *cfg, opening in OPENING_CASES:
+        if only and name not in only:
+            continue
+        fx = ref_selfplay_puct(*cfg, opening=opening)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "first move", fx["actions"][0], "evals", fx["evaluator_calls"], flush=True)
     for name, *cfg in SINGLE_CASES:
         if only and name not in only:
             continue
