@@ -8,9 +8,9 @@ datasets `boards_k` (board dtype), `policies_k` (f32), `values_k` (f32) with `va
 Instead of N worker processes + a shared-memory inference server (Self_Play.py:334-400, Client_Server.py) all games run
 concurrently on the GPU; `num_workers` therefore only bounds nothing here — the concurrency is `n_games`.
 
-Storage: the reference writes HDF5 through h5py.  h5py is not installed in this image, so `ReplayStore` uses h5py when
-it is importable and otherwise an .npz directory with the SAME dataset names / dtypes / shapes (SURVEY.md §8f ranks the
-libhdf5 writer as the next row).
+Storage: the reference writes HDF5 through h5py.  h5py is not installed in this image, so `ReplayStore` uses h5py when it is
+importable and otherwise the system libhdf5 through h5io.py (ctypes) — a real `Self_Play_Data.h5` with the same dataset
+names / dtypes / shapes / libver either way.
 """
 import os
 
@@ -20,43 +20,46 @@ from .engine import EVAL_HASH, EVAL_RESNET, SEARCH_GUMBEL, SEARCH_PUCT, SelfPlay
 
 
 class ReplayStore:
-    """`Self_Play_Data.h5` look-alike: game_stats + boards_k / policies_k / values_k (Self_Play.py:178-208)."""
+    """`Self_Play_Data.h5`: game_stats + boards_k / policies_k / values_k (Self_Play.py:178-208).  Backend: h5py when installed,
+    else libhdf5 through h5io.py (a real HDF5 file either way), else — no HDF5 library at all — an .npy directory."""
 
     def __init__(self, folder_path):
         self.folder = folder_path
         try:
             import h5py  # noqa: F401
-            self.h5 = True
+            self.backend = "h5py"
         except ImportError:
-            self.h5 = False
-        self.path = os.path.join(folder_path, "Self_Play_Data.h5" if self.h5 else "Self_Play_Data.npzdir")
+            from . import h5io
+            self.backend = "libhdf5" if h5io.available() else "npy"
+        self.path = os.path.join(folder_path, "Self_Play_Data.h5" if self.backend != "npy" else "Self_Play_Data.npzdir")
+
+    def _open(self, mode):
+        if self.backend == "h5py":
+            import h5py
+            return _H5pyAdapter(h5py.File(self.path, mode, libver="latest"))
+        from .h5io import H5File
+        return H5File(self.path, mode)
 
     def exists(self):
         return os.path.exists(self.path)
 
     def create(self):
         os.makedirs(self.folder, exist_ok=True)
-        if self.h5:
-            import h5py
-            with h5py.File(self.path, "w", libver="latest") as f:      # Connect4/main.py:83-86
-                f.create_dataset("game_stats", maxshape=(6,), dtype=np.uint32, data=np.zeros(6, np.uint32))
-        else:
+        if self.backend == "npy":
             os.makedirs(self.path, exist_ok=True)
             np.save(os.path.join(self.path, "game_stats.npy"), np.zeros(6, np.uint32))
+            return
+        with self._open("w") as f:                                    # <Game>/main.py:83-86
+            f.create_dataset("game_stats", np.zeros(6, np.uint32), maxshape=(6,), dtype=np.uint32)
 
     def game_stats(self):
-        if self.h5:
-            import h5py
-            with h5py.File(self.path, "r") as f:
-                return np.array(f["game_stats"])
-        return np.load(os.path.join(self.path, "game_stats.npy"))
+        return self.read("game_stats")
 
     def n_datasets(self):
-        if self.h5:
-            import h5py
-            with h5py.File(self.path, "r") as f:
-                return len(f.keys()) - 1
-        return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
+        if self.backend == "npy":
+            return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
+        with self._open("r") as f:
+            return len(f.keys()) - 1
 
     def append_game(self, boards_aug, policies_aug, values_aug, game_length, n_positions, winner):
         """One finished game: arrays [n_aug, T, ...] (Self_Play.py:174-208)."""
@@ -66,27 +69,51 @@ class ReplayStore:
         stats[2] += 1
         stats[winner + 4] += 1
         k0 = self.n_datasets() // 3                                   # dataset_name = (len(keys) - 1) // 3
-        if self.h5:
-            import h5py
-            with h5py.File(self.path, "r+") as f:
-                f["game_stats"][:] = stats
-                for inc in range(policies_aug.shape[0]):
-                    f.create_dataset(f"boards_{k0 + inc}", maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype, data=boards_aug[inc])
-                    f.create_dataset(f"policies_{k0 + inc}", maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32, data=policies_aug[inc])
-                    f.create_dataset(f"values_{k0 + inc}", maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32, data=values_aug[inc])
-        else:
+        if self.backend == "npy":
             np.save(os.path.join(self.path, "game_stats.npy"), stats)
             for inc in range(policies_aug.shape[0]):
                 np.save(os.path.join(self.path, f"boards_{k0 + inc}.npy"), boards_aug[inc])
                 np.save(os.path.join(self.path, f"policies_{k0 + inc}.npy"), policies_aug[inc].astype(np.float32))
                 np.save(os.path.join(self.path, f"values_{k0 + inc}.npy"), values_aug[inc].astype(np.float32))
+            return
+        with self._open("r+") as f:
+            f.write("game_stats", stats)
+            for inc in range(policies_aug.shape[0]):
+                f.create_dataset(f"boards_{k0 + inc}", boards_aug[inc], maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype)
+                f.create_dataset(f"policies_{k0 + inc}", policies_aug[inc], maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32)
+                f.create_dataset(f"values_{k0 + inc}", values_aug[inc], maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32)
 
     def read(self, name):
-        if self.h5:
-            import h5py
-            with h5py.File(self.path, "r") as f:
-                return np.array(f[name])
-        return np.load(os.path.join(self.path, name + ".npy"))
+        if self.backend == "npy":
+            return np.load(os.path.join(self.path, name + ".npy"))
+        with self._open("r") as f:
+            return f.read(name)
+
+
+class _H5pyAdapter:
+    """h5py.File behind the four calls ReplayStore uses."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.f.close()
+        return False
+
+    def keys(self):
+        return list(self.f.keys())
+
+    def create_dataset(self, name, data, maxshape=None, dtype=None):
+        self.f.create_dataset(name, maxshape=maxshape, dtype=dtype, data=data, chunks=None)
+
+    def write(self, name, data):
+        self.f[name][...] = data
+
+    def read(self, name):
+        return np.array(self.f[name])
 
 
 def record_to_samples(game_class, rec):

@@ -145,3 +145,32 @@ def test_two_rank_sharding_and_counter_reduce_gloo(tmp_path, oracle):
         assert o["T"] == T and o["winner"] == winner and o["actions"].tolist() == actions
     tot = out[0][1]
     assert tot[0] == max(T for _, T, _, _ in games) and tot[1] == sum(T for _, T, _, _ in games) and tot[2] == 6
+
+
+def test_replay_file_is_real_hdf5_with_the_reference_schema(tmp_path):
+    """Self_Play_Data.h5 written through libhdf5 (h5io.py): read back, and cross-checked by the HDF5 command line tools."""
+    import shutil
+    from grok_alpha_zero_amd import h5io
+    from grok_alpha_zero_amd.self_play import ReplayStore
+    if not h5io.available():
+        pytest.skip("no libhdf5 on this machine")
+    store = ReplayStore(str(tmp_path / "3"))
+    assert store.backend in ("h5py", "libhdf5")
+    store.create()
+    rng = np.random.default_rng(0)
+    b = rng.integers(-1, 2, size=(2, 11, 6, 7, 4)).astype(np.int8); p = rng.random((2, 11, 7)).astype(np.float32)
+    v = rng.random((2, 11, 1)).astype(np.float32)
+    store.append_game(b, p, v, 11, 11, 1)
+    store.append_game(b[:, :5], p[:, :5], v[:, :5], 5, 5, 0)
+    gs = store.game_stats()
+    assert gs.dtype == np.uint32 and gs.tolist() == [11, 16, 2, 0, 1, 1]
+    with store._open("r") as f:
+        keys = f.keys()
+    assert sorted(keys) == sorted(["game_stats"] + [f"{n}_{k}" for k in range(4) for n in ("boards", "policies", "values")])
+    np.testing.assert_array_equal(store.read("boards_1"), b[1]); assert store.read("boards_1").dtype == np.int8
+    np.testing.assert_array_equal(store.read("policies_2"), p[0, :5]); assert store.read("values_3").shape == (5, 1)
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        out = subprocess.run([h5dump, "-H", store.path], capture_output=True, text=True).stdout
+        assert 'DATASET "boards_0"' in out and "H5T_STD_I8LE" in out and "H5T_IEEE_F32LE" in out and "H5T_STD_U32LE" in out
+        assert "( 11, 6, 7, 4 ) / ( H5S_UNLIMITED, 6, 7, 4 )" in out
