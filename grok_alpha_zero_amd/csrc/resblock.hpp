@@ -25,9 +25,11 @@ struct ResBlockArgs {
     const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
     const float* b2;                              // conv2 bias
     int M, H, W;
+    unsigned long long* stamps;                   // diagnostic: [workgroup][RB_STAMPS]: 32 wall-clock ticks (100 MHz) + 32 shader-clock counts of wave 0, or null
 };
 
-constexpr int RB_ROWS = 256, RB_THREADS = 512;
+constexpr int RB_ROWS = 256, RB_THREADS = 512, RB_STAMPS = 64;
+#define RB_STAMP(i) do { if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * RB_STAMPS + (i)] = wall_clock64(); a.stamps[(size_t)blockIdx.x * RB_STAMPS + 32 + (i)] = clock64(); } } while (0)
 
 __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
     constexpr int CIN = 128, BN = 128, SLOTS = 16, WN = 2, TM = 2, TN = 2;
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
     const int h = a.W + 1, HW = a.H * a.W, bmo = RB_ROWS - 2 * h;
     const long m0 = (long)blockIdx.x * bmo;
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
+    RB_STAMP(0);
 
     // ---- 1. image of x: image row q <-> global row m0 - 2h + q, q in [0, 256 + 2h)
     const int n_aslots = (RB_ROWS + 2 * h) * SLOTS;
@@ -79,25 +82,37 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
     int bbase[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bbase[tn] = lhi * BN + (wn * TN + tn) * 32 + l31;
+    // per-thread parameters, fetched while the DMA is in flight (a load inside a later loop costs an L2 round trip there).
+    // Transform: slot i = tid + 512 * it keeps sp and (lr & 15), so one thread always works on the same 8 channels.
+    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
+    float ps1[8], pt1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps1[j] = a.s1[tch0 + j]; pt1[j] = a.t1[tch0 + j]; }
+    float ps2[TN], pt2[TN], pb2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { const int col = (wn * TN + tn) * 32 + l31; ps2[tn] = a.s2[col]; pt2[tn] = a.t2[col]; pb2[tn] = a.b2[col]; }
 
     __syncthreads();                                // x image + slice 0 landed
+    RB_STAMP(1);
 
     // ---- 2. in-place pre-activation of the image: relu(x * s1 + t1)
     for (int i = tid; i < n_aslots; i += RB_THREADS) {
-        const int lr = i / SLOTS, sp = i % SLOTS, ch0 = (sp ^ (lr & 15)) * 8;
         uint4 v = As[i];
         unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = fmaxf(__uint_as_float(w[j] << 16) * a.s1[ch0 + 2 * j] + a.t1[ch0 + 2 * j], 0.0f);
-            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * a.s1[ch0 + 2 * j + 1] + a.t1[ch0 + 2 * j + 1], 0.0f);
+            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
+            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
             w[j] = pack_bf16(lo, hi);
         }
         As[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __syncthreads();
+    RB_STAMP(2);
 
     f32x16 acc[TM][TN];
+    constexpr int EPI_IT = RB_ROWS / (RB_THREADS / 16);
+    uint4 resv[EPI_IT];
     for (int conv = 0; conv < 2; ++conv) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
                 }
             }
             __syncthreads();                        // next slice landed; everyone is done with this slice (and, at tap 8, with the image)
+            RB_STAMP(3 + sl);
         }
         if (conv == 0) {
             // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int col = (wn * TN + tn) * 32 + l31;
-                    const float s2 = a.s2[col], t2 = a.t2[col];
+                    const float s2 = ps2[tn], t2 = pt2[tn];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -163,6 +179,14 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
                     }
                 }
             __syncthreads();
+            RB_STAMP(21);
+            // residual rows of this thread's epilogue slots: issued now, consumed after conv2 (L2 round trips hidden)
+#pragma unroll
+            for (int it = 0; it < EPI_IT; ++it) {
+                long gr = m0 + tid / 16 + it * (RB_THREADS / 16);
+                gr = gr < a.M ? gr : (long)a.M - 1;
+                resv[it] = *reinterpret_cast<const uint4*>(a.xin + (size_t)gr * BN + (tid % 16) * 8);
+            }
         }
     }
 
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = (wn * TN + tn) * 32 + l31;
-            const float tA = a.b2[col];
+            const float tA = pb2[tn];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -182,20 +206,414 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
             }
         }
     __syncthreads();
+    RB_STAMP(22);
     const int chunk = tid % 16, r0 = tid / 16;
-    for (int row = r0; row < bmo; row += RB_THREADS / 16) {
+#pragma unroll
+    for (int it = 0; it < EPI_IT; ++it) {
+        const int row = r0 + it * (RB_THREADS / 16);
         const long gr = m0 + row;
-        if (gr >= a.M) break;
+        if (row >= bmo || gr >= a.M) break;
         const float4 c0 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8]);
         const float4 c1 = *reinterpret_cast<const float4*>(&Ct[row * CT + chunk * 8 + 4]);
         float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         const size_t o = (size_t)gr * BN + chunk * 8;
-        const uint4 rv = *reinterpret_cast<const uint4*>(a.xin + o);
-        const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+        const unsigned rw[4] = {resv[it].x, resv[it].y, resv[it].z, resv[it].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(rw[j] << 16); v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u); }
         *reinterpret_cast<uint4*>(a.xout + o) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
     }
+    RB_STAMP(23);
+}
+
+// ---- k_resblock2: the same block with the weights OUT of LDS.  Stamps of k_resblock (tools/rb_stamps.py) showed a tap at
+// 3460 cycles against 2048 of pure MFMA: ~900 go to issuing the weight LDS-DMA (all eight waves at once, right after the
+// barrier) and ~500 to the per-tap barrier itself.  Here each wave owns 128 rows x 32 output channels (TM = 4, TN = 1) and
+// loads ITS B fragments straight from global memory (L2-resident, fragment order = one coalesced 16-byte load per lane and
+// k-step) into registers, one whole tap ahead.  The activation image is read-only during a conv, so the tap loop has no
+// barrier at all: waves drift freely and the two waves of a SIMD fill each other's stalls.  L2 -> CU weight traffic doubles
+// (64 KB per tap and workgroup), LDS holds the image only (74 KB); the epilogue goes through a 128-row fp32 tile twice.
+__global__ __launch_bounds__(RB_THREADS, 2) void k_resblock2(ResBlockArgs a) {
+    constexpr int BN = 128, SLOTS = 16, TM = 4, KS = 8;
+    constexpr int AROWS = CONV_AROWS_256, ZROW = AROWS - 1, BSL = BN * SLOTS;
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
+    const int h = a.W + 1, HW = a.H * a.W, bmo = RB_ROWS - 2 * h;
+    const long m0 = (long)blockIdx.x * bmo;
+    const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
+    const int col = wn * 32 + l31;
+    RB_STAMP(0);
+
+    // ---- 1. image of x: image row q <-> global row m0 - 2h + q
+    const int n_aslots = (RB_ROWS + 2 * h) * SLOTS;
+    for (int base = wave * 64; base < n_aslots; base += RB_THREADS) {
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+        long gr = m0 - 2 * h + lr;
+        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
+    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+
+    // weights of the first tap, parameters
+    uint4 bfr[2][KS];
+    const uint4* wl = reinterpret_cast<const uint4*>(a.w1) + lhi * BN + col;      // + (ks * 2) * BN per k-step, + BSL per tap
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[0][ks] = wl[ks * 2 * BN];
+    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
+    float ps1[8], pt1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps1[j] = a.s1[tch0 + j]; pt1[j] = a.t1[tch0 + j]; }
+    const float ps2 = a.s2[col], pt2 = a.t2[col], pb2 = a.b2[col];
+
+    // per-lane geometry: conv1 row j <-> global m0 - h + j ; conv2 row i <-> global m0 + i
+    int lrow[TM]; unsigned vmask[2][TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wm * TM + tm) * 32 + l31;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const long gr = m0 + lrow[tm] - (which == 0 ? h : 0);
+            unsigned m = 0;
+            if (gr >= 0 && gr < a.M) {
+                const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    m |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
+                }
+            }
+            vmask[which][tm] = m;
+        }
+    }
+    __syncthreads();                                // x image landed
+    RB_STAMP(1);
+
+    // ---- 2. in-place pre-activation of the image: relu(x * s1 + t1)
+    for (int i = tid; i < n_aslots; i += RB_THREADS) {
+        uint4 v = As[i];
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
+            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
+            w[j] = pack_bf16(lo, hi);
+        }
+        As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    RB_STAMP(2);
+
+    f32x16 acc[TM];
+    constexpr int EPI_IT = RB_ROWS / (RB_THREADS / 16);
+    uint4 resv[EPI_IT];
+#pragma unroll
+    for (int sl = 0; sl < 18; ++sl) {
+        const int conv = sl / 9, tap = sl % 9;
+        if (tap == 0) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
+        }
+        if (sl + 1 < 18) {                          // B fragments of the next tap: in flight during this tap's MFMAs
+            const uint4* wn4 = reinterpret_cast<const uint4*>(sl + 1 < 9 ? a.w1 : a.w2) + (size_t)((sl + 1) % 9) * BSL + lhi * BN + col;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bfr[(sl + 1) & 1][ks] = wn4[ks * 2 * BN];
+        }
+        if (sl == 14) {                             // residual rows of this thread's epilogue slots (L2 round trip hidden)
+#pragma unroll
+            for (int it = 0; it < EPI_IT; ++it) {
+                long gr = m0 + tid / 16 + it * (RB_THREADS / 16);
+                gr = gr < a.M ? gr : (long)a.M - 1;
+                resv[it] = *reinterpret_cast<const uint4*>(a.xin + (size_t)gr * BN + (tid % 16) * 8);
+            }
+        }
+        const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
+        int abase[TM], axor[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const bool ok = (vmask[conv][tm] >> tap) & 1u;
+            const int ar = ok ? lrow[tm] + h + off : ZROW;
+            abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+        }
+        uint4 afr[2][TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+            }
+            const bf16x8 bf = *reinterpret_cast<bf16x8*>(&bfr[sl & 1][ks]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf, acc[tm], 0, 0, 0);
+        }
+        RB_STAMP(3 + sl);
+        if (sl == 8) {
+            __syncthreads();                        // every wave is done with the x image
+            // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
+            bf16_t* Hs = reinterpret_cast<bf16_t*>(As);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float v = fmaxf(acc[tm][r] * ps2 + pt2, 0.0f);
+                    Hs[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (bf16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+                }
+            __syncthreads();
+            RB_STAMP(21);
+        }
+    }
+    __syncthreads();                                // every wave is done with the h image
+
+    // ---- 6. epilogue, 128 rows at a time through an fp32 tile over the image region: + bias + residual, rows [m0, m0 + bmo)
+    constexpr int CT = BN + 4;
+    float* Ct = reinterpret_cast<float*>(lds);
+    static_assert((size_t)128 * CT * 4 <= (size_t)AROWS * SLOTS * 16, "epilogue tile must fit in the image region");
+    const int chunk = tid % 16, r0 = tid / 16;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    Ct[row * CT + col] = acc[tm][r] + pb2;
+                }
+        }
+        __syncthreads();
+        if (pass == 0) RB_STAMP(22);
+#pragma unroll
+        for (int it4 = 0; it4 < EPI_IT / 2; ++it4) {
+            const int it = pass * (EPI_IT / 2) + it4, rl = r0 + it4 * (RB_THREADS / 16), row = pass * 128 + rl;
+            const long gr = m0 + row;
+            if (row < bmo && gr < a.M) {
+                const float4 c0 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8 + 4]);
+                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const size_t o = (size_t)gr * BN + chunk * 8;
+                const unsigned rw[4] = {resv[it].x, resv[it].y, resv[it].z, resv[it].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(rw[j] << 16); v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u); }
+                *reinterpret_cast<uint4*>(a.xout + o) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            }
+        }
+        if (pass == 0) __syncthreads();
+    }
+    RB_STAMP(23);
+}
+
+// ---- k_resblock3: k_resblock2's barrier-free taps in 256-thread workgroups, TWO per CU.  k_resblock2's stamps: taps at
+// ~84 % of the MFMA rate, but 37 % of a workgroup's life (image DMA wait, transform, h write, epilogue) leaves the matrix
+// cores idle because one 8-wave workgroup owns the CU.  Here a workgroup is 4 waves (one per SIMD), each 128 rows x 64
+// channels (TM = 4, TN = 2: 8 MFMAs per 4 LDS fragment reads); LDS is the 74-KB image only, so two workgroups share a CU
+// and one's serial phases hide behind the other's MFMAs.  B fragments: a four-k-step register ring fed from L2.
+// TM picks the tile height (ROWS = 64 * TM image rows computed, ROWS - 2(W+1) of them valid outputs): the host takes the TM
+// whose tile count fills whole rounds of 2 workgroups x 256 CUs best (Connect4, 4096 games: TM = 3 -> 978 tiles = 1.91 rounds).
+constexpr int RB3_THREADS = 256;
+template <int TM> constexpr int rb3_rows() { return 64 * TM; }
+template <int TM> constexpr size_t rb3_lds_bytes() { return (size_t)(rb3_rows<TM>() + 2 * CONV_HALO_MAX + 1) * 256; }
+template <int TM, int RING>
+__global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
+    constexpr int BN = 128, SLOTS = 16, TN = 2, KS = 8, ROWS = rb3_rows<TM>();
+    constexpr int AROWS = ROWS + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1, BSL = BN * SLOTS;
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int h = a.W + 1, HW = a.H * a.W, bmo = ROWS - 2 * h;
+    const long m0 = (long)blockIdx.x * bmo;
+    const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
+    const int col0 = wn * 64 + l31;                 // + 32 * tn
+    RB_STAMP(0);
+
+    // ---- 1. image of x: image row q <-> global row m0 - 2h + q
+    const int n_aslots = (ROWS + 2 * h) * SLOTS;
+    for (int base = wave * 64; base < n_aslots; base += RB3_THREADS) {
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+        long gr = m0 - 2 * h + lr;
+        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
+    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+
+    // B ring: fragment (global k-step g = sl * 8 + ks, tn) lives in bfr[g % RING][tn]
+    uint4 bfr[RING][TN];
+    const uint4* w1 = reinterpret_cast<const uint4*>(a.w1) + lhi * BN + col0;
+    const uint4* w2 = reinterpret_cast<const uint4*>(a.w2) + lhi * BN + col0;
+#pragma unroll
+    for (int g = 0; g < RING; ++g)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = w1[g * 2 * BN + tn * 32];
+    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
+    float ps1[8], pt1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps1[j] = a.s1[tch0 + j]; pt1[j] = a.t1[tch0 + j]; }
+    float ps2[TN], pt2[TN], pb2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { ps2[tn] = a.s2[col0 + tn * 32]; pt2[tn] = a.t2[col0 + tn * 32]; pb2[tn] = a.b2[col0 + tn * 32]; }
+
+    int lrow[TM]; unsigned vmask[TM];               // bits 0-8: conv1 taps, 9-17: conv2 taps
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wm * TM + tm) * 32 + l31;
+        unsigned mm = 0;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const long gr = m0 + lrow[tm] - (which == 0 ? h : 0);
+            if (gr >= 0 && gr < a.M) {
+                const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << (which * 9 + t);
+                }
+            }
+        }
+        vmask[tm] = mm;
+    }
+    __syncthreads();                                // x image landed
+    RB_STAMP(1);
+
+    // ---- 2. in-place pre-activation of the image: relu(x * s1 + t1)
+    for (int i = tid; i < n_aslots; i += RB3_THREADS) {
+        uint4 v = As[i];
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
+            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
+            w[j] = pack_bf16(lo, hi);
+        }
+        As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    RB_STAMP(2);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int sl = 0; sl < 18; ++sl) {
+        const int tap = sl % 9;
+        if (tap == 0) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+        }
+        const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
+        int abase[TM], axor[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const bool ok = (vmask[tm] >> sl) & 1u;
+            const int ar = ok ? lrow[tm] + h + off : ZROW;
+            abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+        }
+        uint4 afr[2][TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1, g = sl * KS + ks;
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+            }
+            bf16x8 bf[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[g % RING][tn]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
+            if (g + RING < 18 * KS) {               // refill this ring slot with k-step g + RING (possibly of the next tap / conv)
+                const int g2 = g + RING, sl2 = g2 / KS, ks2 = g2 % KS;
+                const uint4* wsrc = (sl2 < 9 ? w1 : w2) + (size_t)(sl2 % 9) * BSL + ks2 * 2 * BN;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bfr[g % RING][tn] = wsrc[tn * 32];
+            }
+        }
+        RB_STAMP(3 + sl);
+        if (sl == 8) {
+            __syncthreads();                        // every wave is done with the x image
+            // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
+            bf16_t* Hs = reinterpret_cast<bf16_t*>(As);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = col0 + tn * 32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const float v = fmaxf(acc[tm][tn][r] * ps2[tn] + pt2[tn], 0.0f);
+                        Hs[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (bf16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+                    }
+                }
+            __syncthreads();
+            RB_STAMP(21);
+        }
+    }
+    // residual rows of all this thread's epilogue slots: one L2 round trip, hidden behind the barrier and the tile writes
+    // (the B ring and the A fragments are dead by now, so the registers are there)
+    uint4 resv[4 * TM];
+#pragma unroll
+    for (int q = 0; q < 4 * TM; ++q) {
+        long gr = m0 + (q / (2 * TM)) * (ROWS / 2) + tid / 16 + (q % (2 * TM)) * (RB3_THREADS / 16);
+        gr = gr < a.M ? gr : (long)a.M - 1;
+        resv[q] = *reinterpret_cast<const uint4*>(a.xin + (size_t)gr * BN + (tid % 16) * 8);
+    }
+    __syncthreads();                                // every wave is done with the h image
+
+    // ---- 6. epilogue, half the rows at a time through an fp32 tile over the image region: + bias + residual, rows [m0, m0 + bmo)
+    constexpr int CT = BN + 4, HR = ROWS / 2;
+    float* Ct = reinterpret_cast<float*>(lds);
+    static_assert((size_t)HR * CT * 4 <= (size_t)AROWS * SLOTS * 16, "epilogue tile must fit in the image region");
+    const int chunk = tid % 16, r0 = tid / 16;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        Ct[row * CT + col0 + tn * 32] = acc[tm][tn][r] + pb2[tn];
+                    }
+        }
+        __syncthreads();
+        if (pass == 0) RB_STAMP(22);
+#pragma unroll
+        for (int q = 0; q < 2 * TM; ++q) {          // 2 * TM rows per thread and pass
+            const int rl = r0 + q * (RB3_THREADS / 16), row = pass * HR + rl;
+            const long gr = m0 + row;
+            if (row < bmo && gr < a.M) {
+                const float4 c0 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8 + 4]);
+                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const size_t o = (size_t)gr * BN + chunk * 8;
+                const uint4 rq = resv[pass * 2 * TM + q];
+                const unsigned rw[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(rw[j] << 16); v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u); }
+                *reinterpret_cast<uint4*>(a.xout + o) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            }
+        }
+        if (pass == 0) __syncthreads();
+    }
+    RB_STAMP(23);
 }
 
 }  // namespace gaz

@@ -18,6 +18,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "evaluator.hpp"
 #include "conv3x3.hpp"
 #include "netops.hpp"
@@ -86,6 +87,91 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
     }
 }
 
+// ---- stem on the matrix cores.  D[channel][cell] = W'[channel][k] * X[k][cell], k = tap * 4 + plane (36, padded to 48).
+// The int8 planes are exact in bf16; the fp32 weights (BN scale folded in) are split into bf16 hi + lo halves that
+// share the activation operand (6 k-steps), which keeps ~16 mantissa bits.  One wave = one 32-cell tile x all 128
+// channels; each lane ends up with 4 consecutive channels of its own cell per accumulator quad -> 8-byte stores.
+// GELU is x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8, output is bf16).
+struct StemMArgs { const int8_t* in; const uint4* wfrag; const float* shift; bf16_t* out; int M, H, W, tiles_per_wave; };
+
+__device__ __forceinline__ float gelu_as(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    p = 0.5f * p * __expf(-x * x);                 // 0.5 * erfc(x)
+    return v * (v < 0.0f ? p : 1.0f - p);
+}
+
+__device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two small integers -> packed bf16 (exact)
+    return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+}
+
+__global__ __launch_bounds__(256) void k_stem_mfma(StemMArgs a) {
+    __shared__ uint4 wl[6 * 2 * 128];              // [k-step (3 hi + 3 lo)][k-half][channel] x 8 bf16
+    __shared__ float sh[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    {
+        uint4 wv[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wv[c] = a.wfrag[tid + 256 * c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wl[tid + 256 * c] = wv[c];
+    }
+    if (tid < 128) sh[tid] = a.shift[tid];
+    __syncthreads();
+    const int* in32 = reinterpret_cast<const int*>(a.in);
+    const int HW = a.H * a.W;
+    for (int t = 0; t < a.tiles_per_wave; ++t) {
+        const long tile = ((long)blockIdx.x * 4 + wave) * a.tiles_per_wave + t;
+        if (tile * 32 >= a.M) break;               // wave-uniform
+        const long gr = tile * 32 + l31;
+        const bool rok = gr < a.M;
+        const int cell = (int)(gr % HW), y = cell / a.W, x = cell % a.W;
+        uint4 bfr[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            unsigned d[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tap = ks * 4 + lhi * 2 + h;
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                int packed = 0;
+                if (rok && tap < 9 && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
+                    packed = in32[gr + dy * a.W + dx];
+                d[2 * h] = s8x2_to_bf16x2((int)(int8_t)(packed & 0xFF), (int)(int8_t)((packed >> 8) & 0xFF));
+                d[2 * h + 1] = s8x2_to_bf16x2((int)(int8_t)((packed >> 16) & 0xFF), packed >> 24);
+            }
+            bfr[ks] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        f32x16 acc[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
+#pragma unroll
+        for (int ks6 = 0; ks6 < 6; ++ks6) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&bfr[ks6 % 3]);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const uint4 av = wl[(ks6 * 2 + lhi) * 128 + tm * 32 + l31];
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&av), bf, acc[tm], 0, 0, 0);
+            }
+        }
+        if (!rok) continue;
+        // D rows (channels) of lane: (r & 3) + 8 * (r >> 2) + 4 * lhi, column (cell) = l31
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ch0 = tm * 32 + rg * 8 + lhi * 4;
+                const float4 s4 = *reinterpret_cast<const float4*>(&sh[ch0]);
+                const float v0 = gelu_as(acc[tm][rg * 4 + 0] + s4.x), v1 = gelu_as(acc[tm][rg * 4 + 1] + s4.y);
+                const float v2 = gelu_as(acc[tm][rg * 4 + 2] + s4.z), v3 = gelu_as(acc[tm][rg * 4 + 3] + s4.w);
+                *reinterpret_cast<uint2*>(a.out + (size_t)gr * 128 + ch0) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+            }
+    }
+}
+
 // ---- heads: Dense(F -> 128) + folded BN + ReLU, fp32.  Block = 128 threads (one output each), 8 positions at a time.
 __global__ __launch_bounds__(128) void k_dense1(const float* feat, const float* w, const float* scale, const float* shift,
                                                 float* out, int B, int F) {
@@ -113,23 +199,50 @@ __global__ __launch_bounds__(128) void k_dense1(const float* feat, const float* 
 // (v_mfma_f32_32x32x2_f32): block = 32 positions x 128 outputs, 4 waves x 32 columns; blockIdx.y = head.
 struct Dense1Args { const float* feat[2]; const float* w[2]; const float* scale[2]; const float* shift[2]; float* out[2]; int B, F; };
 __global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
-    extern __shared__ float fl[];                  // [32][F + 1]
-    const int head = blockIdx.y, b0 = blockIdx.x * 32, F = a.F, FP = F + 1;
+    extern __shared__ float fl[];                  // [32][FP], FP = F rounded up to 16, + 1 (zero-padded columns)
+    constexpr int G = 8, D = 4;                    // 16 k per group, four-deep register ring of weight groups
+    const int head = blockIdx.y, b0 = blockIdx.x * 32, F = a.F, NG = (F + 2 * G - 1) / (2 * G), FP = NG * 2 * G + 1;
     const float* feat = a.feat[head]; const float* w = a.w[head];
-    for (int i = threadIdx.x; i < 32 * F; i += 256) {
-        const int p = i / F, k = i % F;
-        fl[p * FP + k] = (b0 + p < a.B) ? feat[(size_t)(b0 + p) * F + k] : 0.0f;
+    // one wave per position row, coalesced; loads are unconditional (clamped) and issued six at a time — a plain
+    // load -> store loop costs one L2 round trip per iteration
+    for (int p = threadIdx.x >> 6; p < 32; p += 4) {
+        const size_t rb = (size_t)min(b0 + p, a.B - 1) * F;
+        const bool rok = b0 + p < a.B;
+        for (int kb = threadIdx.x & 63; kb < FP; kb += 64 * 6) {
+            float v[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = feat[rb + min(kb + 64 * c, F - 1)];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { const int k = kb + 64 * c; if (k < FP) fl[p * FP + k] = (rok && k < F) ? v[c] : 0.0f; }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, n = wave * 32 + l31;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < F; k += 2) {               // A[i = l31][k + lhi], B[k + lhi][j = l31]
-        const float av = fl[l31 * FP + k + lhi];
-        const float bv = w[(size_t)(k + lhi) * 128 + n];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    // A[i = l31][k + lhi], B[k + lhi][j = l31].  The weights come from L2 (~1 us away under load): the next three groups
+    // are in flight while a group multiplies.  Loads past the last row are clamped (their A columns are zero).
+    float bq[D][G];
+    auto ldg = [&](int g, float* dst) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) { const int k = min(g * 2 * G + 2 * j + lhi, F - 1); dst[j] = w[(size_t)k * 128 + n]; }
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) ldg(d, bq[d]);
+    for (int g0 = 0; g0 < NG; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int g = g0 + d;
+            ldg(g + D - 1, bq[(d + D - 1) % D]);
+            if (g < NG) {                           // wave-uniform
+                float av[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) av[j] = fl[l31 * FP + g * 2 * G + 2 * j + lhi];
+#pragma unroll
+                for (int j = 0; j < G; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[d][j], acc, 0, 0, 0);
+            }
+        }
     }
     const float s = a.scale[head][n], t = a.shift[head][n];
 #pragma unroll
@@ -146,41 +259,72 @@ struct TailArgs {
     const float* v_w2; const float* v_b2; const float* v_w3; const float* v_b3;
     float* policy; float* value; int B, A, logits;
 };
-__global__ __launch_bounds__(64) void k_tail(TailArgs a) {
-    __shared__ float x[128]; __shared__ float h[64]; __shared__ float lg[64];
-    const int b = blockIdx.x, l = threadIdx.x;
-    for (int head = 0; head < 2; ++head) {
-        const float* d1 = head == 0 ? a.p_d1 : a.v_d1;
-        const float* w2 = head == 0 ? a.p_w2 : a.v_w2; const float* b2 = head == 0 ? a.p_b2 : a.v_b2;
-        const float* w3 = head == 0 ? a.p_w3 : a.v_w3; const float* b3 = head == 0 ? a.p_b3 : a.v_b3;
-        const int nout = head == 0 ? a.A : 1;
-        x[l] = d1[(size_t)b * 128 + l]; x[l + 64] = d1[(size_t)b * 128 + 64 + l];
-        __syncthreads();
-        float acc = b2[l];
-        for (int k = 0; k < 128; ++k) acc += x[k] * w2[k * 64 + l];
-        h[l] = acc;
-        __syncthreads();
-        if (l < nout) {
-            float z = b3[l];
-            for (int k = 0; k < 64; ++k) z += h[k] * w3[k * nout + l];
-            lg[l] = z;
+// 16 positions per block (8 threads each), blockIdx.y = head; Dense(128 -> 64) weights staged in LDS once per block.
+// Summation order per output is k ascending starting from the bias, independent of the batch composition.
+__global__ __launch_bounds__(128) void k_tail(TailArgs a) {
+    __shared__ float w2l[128 * 64]; __shared__ float xl[16][128]; __shared__ float hl[16][64]; __shared__ float lg[16][64];
+    __shared__ float w3l[64 * 8];                  // Dense(64 -> nout) weights when nout <= 8 (Connect4: 7 | 1)
+    const int head = blockIdx.y, tid = threadIdx.x, p = tid >> 3, q = tid & 7, b0 = blockIdx.x * 16;
+    const float* d1 = head == 0 ? a.p_d1 : a.v_d1;
+    const float* w2 = head == 0 ? a.p_w2 : a.v_w2; const float* b2 = head == 0 ? a.p_b2 : a.v_b2;
+    const float* w3 = head == 0 ? a.p_w3 : a.v_w3; const float* b3 = head == 0 ? a.p_b3 : a.v_b3;
+    const int nout = head == 0 ? a.A : 1;
+    {   // 16 + 4 float4 per thread, all loads issued before the first LDS store
+        float4 wv[16], xv[4];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wv[c] = reinterpret_cast<const float4*>(w2)[tid + 128 * c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = tid + 128 * c, pp = min(b0 + i / 32, a.B - 1);
+            xv[c] = reinterpret_cast<const float4*>(d1 + (size_t)pp * 128)[i % 32];
         }
-        __syncthreads();
-        if (head == 0) {
-            if (l < nout) {
-                if (a.logits) a.policy[(size_t)b * a.A + l] = lg[l];
-                else {
-                    float mx = lg[0];
-                    for (int k = 1; k < nout; ++k) mx = fmaxf(mx, lg[k]);
-                    float sum = 0.f;
-                    for (int k = 0; k < nout; ++k) sum += expf(lg[k] - mx);
-                    a.policy[(size_t)b * a.A + l] = expf(lg[l] - mx) / sum;
-                }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) reinterpret_cast<float4*>(w2l)[tid + 128 * c] = wv[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) reinterpret_cast<float4*>(&xl[0][0])[tid + 128 * c] = xv[c];
+        if (nout <= 8) {
+            float w3v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w3v[c] = w3[min(tid + 128 * c, 64 * nout - 1)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w3l[tid + 128 * c] = w3v[c];
+        }
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = b2[q * 8 + j];
+    for (int k = 0; k < 128; ++k) {
+        const float xv = xl[p][k];
+        const float4 wa = *reinterpret_cast<const float4*>(&w2l[k * 64 + q * 8]), wb = *reinterpret_cast<const float4*>(&w2l[k * 64 + q * 8 + 4]);
+        acc[0] += xv * wa.x; acc[1] += xv * wa.y; acc[2] += xv * wa.z; acc[3] += xv * wa.w;
+        acc[4] += xv * wb.x; acc[5] += xv * wb.y; acc[6] += xv * wb.z; acc[7] += xv * wb.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hl[p][q * 8 + j] = acc[j];
+    __syncthreads();
+    for (int o = q; o < nout; o += 8) {
+        float z = b3[o];
+        if (nout <= 8) { for (int k = 0; k < 64; ++k) z += hl[p][k] * w3l[k * nout + o]; }
+        else { for (int k = 0; k < 64; ++k) z += hl[p][k] * w3[k * nout + o]; }
+        lg[p][o] = z;
+    }
+    __syncthreads();
+    if (b0 + p >= a.B) return;
+    const int b = b0 + p;
+    if (head == 0) {
+        for (int o = q; o < nout; o += 8) {
+            if (a.logits) a.policy[(size_t)b * a.A + o] = lg[p][o];
+            else {
+                float mx = lg[p][0];
+                for (int k = 1; k < nout; ++k) mx = fmaxf(mx, lg[p][k]);
+                float sum = 0.f;
+                for (int k = 0; k < nout; ++k) sum += expf(lg[p][k] - mx);
+                a.policy[(size_t)b * a.A + o] = expf(lg[p][o] - mx) / sum;
             }
-        } else if (l == 0) {
-            a.value[b] = tanhf(lg[0]);
         }
-        __syncthreads();
+    } else if (q == 0) {
+        a.value[b] = tanhf(lg[p][0]);
     }
 }
 
@@ -191,6 +335,8 @@ struct ResNetEvaluator : Evaluator {
     std::map<std::string, bf16_t*> b16;             // device bf16 conv weights by name
     bf16_t *X = nullptr, *Aa = nullptr, *Hh = nullptr, *X2 = nullptr;
     bool fused = true;
+    int stamp_calls = 0;
+    bf16_t* stem_frag = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
     bool loaded = false;
@@ -225,6 +371,21 @@ struct ResNetEvaluator : Evaluator {
         };
         const int Fc = filters, F = HW * 8;
         if (!up_f32("stem.w", 9 * 128 * C) || !up_f32("stem.scale", 128) || !up_f32("stem.shift", 128)) return 1;
+        {   // MFMA stem operand: [6 k-steps (hi, hi, hi, lo, lo, lo)][k-half][channel][8], BN scale folded into the weights
+            if (C != 4) { *err = "stem expects 4 input planes"; return 1; }
+            const float* w = by["stem.w"]->data; const float* sc = by["stem.scale"]->data;
+            std::vector<bf16_t> h(6 * 2 * 128 * 8, 0);
+            for (int ks6 = 0; ks6 < 6; ++ks6) for (int half = 0; half < 2; ++half) for (int ch = 0; ch < 128; ++ch) for (int j = 0; j < 8; ++j) {
+                const int k = (ks6 % 3) * 16 + half * 8 + j;
+                if (k >= 36) continue;
+                const float wv = w[((k / 4) * 128 + ch) * 4 + (k % 4)] * sc[ch];
+                const bf16_t hi = f2bf_host(wv);
+                unsigned hu = (unsigned)hi << 16; float hf; memcpy(&hf, &hu, 4);
+                h[(((size_t)ks6 * 2 + half) * 128 + ch) * 8 + j] = ks6 < 3 ? hi : f2bf_host(wv - hf);
+            }
+            stem_frag = dalloc<bf16_t>(h.size()); if (!stem_frag) { *err = "hipMalloc"; return 1; }
+            hipMemcpy(stem_frag, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        }
         for (int i = 0; i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i);
             if (!up_f32(b + ".bn1.scale", Fc) || !up_f32(b + ".bn1.shift", Fc) || !up_b16(b + ".conv1.w", 9LL * Fc * Fc) ||
@@ -265,7 +426,15 @@ struct ResNetEvaluator : Evaluator {
         StemArgs st; st.in = in; st.w = f32["stem.w"]; st.scale = f32["stem.scale"]; st.shift = f32["stem.shift"];
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
         st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
-        hipLaunchKernelGGL(k_stem, dim3((M + 63) / 64), dim3(256), 0, s, st);
+        if (fused) {
+            StemMArgs sm; sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = f32["stem.shift"]; sm.out = X;
+            sm.M = M; sm.H = H; sm.W = W;
+            const int tiles = (M + 31) / 32;
+            sm.tiles_per_wave = std::max(1, (tiles + 1343) / 2688);     // ~2.7k waves: ten per CU, each amortising the 24-KB weight stage
+            hipLaunchKernelGGL(k_stem_mfma, dim3((tiles + 4 * sm.tiles_per_wave - 1) / (4 * sm.tiles_per_wave)), dim3(256), 0, s, sm);
+        } else {
+            hipLaunchKernelGGL(k_stem, dim3((M + 63) / 64), dim3(256), 0, s, st);
+        }
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
         bf16_t* cur = X;
@@ -273,10 +442,40 @@ struct ResNetEvaluator : Evaluator {
             const std::string b = "block" + std::to_string(i);
             ResBlockArgs r; r.xin = cur; r.xout = cur == X ? X2 : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
             r.s1 = f32[b + ".bn1.scale"]; r.t1 = f32[b + ".bn1.shift"]; r.s2 = f32[b + ".conv1.scale"]; r.t2 = f32[b + ".conv1.shift"];
-            r.b2 = f32[b + ".conv2.bias"]; r.M = M; r.H = H; r.W = W;
-            const int bmo = RB_ROWS - 2 * (W + 1);
+            r.b2 = f32[b + ".conv2.bias"]; r.M = M; r.H = H; r.W = W; r.stamps = nullptr;
+            static const int rbv = getenv("GAZ_RB") ? atoi(getenv("GAZ_RB")) : 3;
+            static const int rb_tm = getenv("GAZ_RB_TM") ? atoi(getenv("GAZ_RB_TM")) : 0;
+            static const int rb_ring = getenv("GAZ_RB_RING") ? atoi(getenv("GAZ_RB_RING")) : 8;
+            // k_resblock3: tile height 64 * TM; take the TM with the least (rounds of 512 workgroups) x (tile cost ~ TM)
+            int tm = rb_tm;
+            if (rbv == 3 && tm == 0) {
+                double best = 1e30;
+                for (int c = 2; c <= 4; ++c) {
+                    const int bm = 64 * c - 2 * (W + 1); const long nt = (M + bm - 1) / bm;
+                    const double cost = (double)((nt + 511) / 512) * c;
+                    if (cost <= best) { best = cost; tm = c; }      // ties: the taller tile (less halo recompute)
+                }
+            }
+            const int bmo = (rbv == 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
-            hipLaunchKernelGGL(k_resblock, dim3((M + bmo - 1) / bmo), dim3(RB_THREADS), lds, s, r);
+            const int nwg = (M + bmo - 1) / bmo;
+            static const char* stamp_path = getenv("GAZ_RB_STAMPS");       // diagnostic: phase stamps of one launch -> file
+            const bool stamp = stamp_path && i == 1 && ++stamp_calls == 3;
+            if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * RB_STAMPS * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * RB_STAMPS * 8, s); }
+            if (rbv == 3) {
+                if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+                else if (tm == 3 && rb_ring == 8) hipLaunchKernelGGL((k_resblock3<3, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+                else if (tm == 3) hipLaunchKernelGGL((k_resblock3<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+                else hipLaunchKernelGGL((k_resblock3<4, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
+            }
+            else if (rbv == 2) hipLaunchKernelGGL(k_resblock2, dim3(nwg), dim3(RB_THREADS), (size_t)CONV_AROWS_256 * 256, s, r);
+            else hipLaunchKernelGGL(k_resblock, dim3(nwg), dim3(RB_THREADS), lds, s, r);
+            if (stamp) {
+                std::vector<unsigned long long> hst((size_t)nwg * RB_STAMPS);
+                hipStreamSynchronize(s);
+                hipMemcpy(hst.data(), r.stamps, hst.size() * 8, hipMemcpyDeviceToHost); hipFree(r.stamps);
+                if (FILE* f = fopen(stamp_path, "wb")) { fwrite(hst.data(), 8, hst.size(), f); fclose(f); }
+            }
             cur = r.xout;
         }
         for (int i = 0; !fused && i < blocks; ++i) {
@@ -293,18 +492,24 @@ struct ResNetEvaluator : Evaluator {
             a.in = cur; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
             a.p_fs = f32["p.bn0.scale"]; a.p_ft = f32["p.bn0.shift"]; a.v_fs = f32["v.bn0.scale"]; a.v_ft = f32["v.bn0.shift"];
             a.p_feat = pfeat; a.v_feat = vfeat;
-            const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
-            hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), dim3((M + 255) / 256), dim3(512), lds, s, a);
+            static const int hv = getenv("GAZ_HEADS_VARIANT") ? atoi(getenv("GAZ_HEADS_VARIANT")) : 0;
+            if (hv == 0) {
+                const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
+                hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), dim3((M + 255) / 256), dim3(512), lds, s, a);
+            } else {
+                const size_t lds = conv_lds_bytes<128, 32, 128, 1>();
+                hipLaunchKernelGGL((k_conv3x3<128, 32, 128, 4, 1, 1, 1, 1, 2, 1>), dim3((M + 127) / 128), dim3(256), lds, s, a);
+            }
         }
         const int F = HW * 8;
         Dense1Args d; d.B = n; d.F = F;
         d.feat[0] = pfeat; d.w[0] = f32["p.d1.w"]; d.scale[0] = f32["p.d1.scale"]; d.shift[0] = f32["p.d1.shift"]; d.out[0] = pd1;
         d.feat[1] = vfeat; d.w[1] = f32["v.d1.w"]; d.scale[1] = f32["v.d1.scale"]; d.shift[1] = f32["v.d1.shift"]; d.out[1] = vd1;
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((n + 31) / 32, 2), dim3(256), (size_t)32 * (F + 1) * 4, s, d);
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((n + 31) / 32, 2), dim3(256), (size_t)32 * ((F + 15) / 16 * 16 + 1) * 4, s, d);
         TailArgs t; t.p_d1 = pd1; t.v_d1 = vd1; t.p_w2 = f32["p.d2.w"]; t.p_b2 = f32["p.d2.bias"]; t.p_w3 = f32["p.d3.w"];
         t.p_b3 = f32["p.d3.bias"]; t.v_w2 = f32["v.d2.w"]; t.v_b2 = f32["v.d2.bias"]; t.v_w3 = f32["v.d3.w"]; t.v_b3 = f32["v.d3.bias"];
         t.policy = policy; t.value = value; t.B = n; t.A = A; t.logits = logits;
-        hipLaunchKernelGGL(k_tail, dim3(n), dim3(64), 0, s, t);
+        hipLaunchKernelGGL(k_tail, dim3((n + 15) / 16, 2), dim3(128), 0, s, t);
     }
 
     bool ready() const override { return loaded; }
