@@ -25,6 +25,8 @@ struct ResBlockArgs {
     const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
     const float* b2;                              // conv2 bias
     int M, H, W;
+    unsigned* cu_slots;                           // [8 XCC][256]: arrival counters per CU (k_resblock3 stagger), or null
+    int stagger_wgs, stagger_ticks;               // workgroups of the first round; delay of every second arrival on a CU (100 MHz ticks)
     unsigned long long* stamps;                   // diagnostic: [workgroup][RB_STAMPS]: 32 wall-clock ticks (100 MHz) + 32 shader-clock counts of wave 0, or null
 };
 
@@ -446,13 +448,20 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
     if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
 
     // B ring: fragment (global k-step g = sl * 8 + ks, tn) lives in bfr[g % RING][tn]
+    // Buffer loads: one VGPR (the lane part of the address) serves every fragment, the slice / k-step part is scalar.
+    // The host puts conv2's weights right behind conv1's, so the 18 slices are one array.
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, 18 * BSL * 16, 0x00020000);
+    const int bvo = (lhi * BN + col0) * 16;
+    auto ldb = [&](int slice, int ks, int tn) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, ((slice * BSL) + ks * 2 * BN + tn * 32) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
     uint4 bfr[RING][TN];
-    const uint4* w1 = reinterpret_cast<const uint4*>(a.w1) + lhi * BN + col0;
-    const uint4* w2 = reinterpret_cast<const uint4*>(a.w2) + lhi * BN + col0;
 #pragma unroll
     for (int g = 0; g < RING; ++g)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = w1[g * 2 * BN + tn * 32];
+        for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = ldb(0, g, tn);
     const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
     float ps1[8], pt1[8];
 #pragma unroll
@@ -480,6 +489,22 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
         }
         vmask[tm] = mm;
     }
+    // Stagger: the two workgroups a CU receives in the first round start in lockstep, so their DMA waits, transforms, h writes
+    // and epilogues coincide and leave the matrix cores idle.  Every second arrival on a CU (HW_ID -> per-CU counter) holds
+    // back for stagger_ticks after its image has landed; later rounds inherit the offset.
+    if (a.cu_slots && (int)blockIdx.x < a.stagger_wgs) {
+        __shared__ unsigned s_order;
+        if (tid == 0) {
+            const unsigned cu = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);        // HW_ID[15:8]: CU, SH, SE
+            const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // XCC_ID[3:0]
+            s_order = atomicAdd(&a.cu_slots[(xcc & 7) * 256 + cu], 1u);
+        }
+        __syncthreads();
+        if (s_order & 1u) {
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)a.stagger_ticks;
+            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     __syncthreads();                                // x image landed
     RB_STAMP(1);
 
@@ -498,53 +523,60 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
     __syncthreads();
     RB_STAMP(2);
 
+    // The tap loops are real loops (code ~10 KB): fully unrolled, the 18 taps are ~60 KB of straight-line code that every
+    // wave streams through the instruction cache exactly once.  Ring slot = ks % RING is then tap-independent.
+    static_assert(KS % RING == 0, "ring slot must not depend on the tap");
     f32x16 acc[TM][TN];
+#pragma unroll                                      // two copies of the tap loop: keeps the h-write address math out of any loop
+    for (int conv = 0; conv < 2; ++conv) {
 #pragma unroll
-    for (int sl = 0; sl < 18; ++sl) {
-        const int tap = sl % 9;
-        if (tap == 0) {
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sl = conv * 9 + tap;
+            const int nsl = sl + 1 < 18 ? sl + 1 : sl;
+            const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+            int abase[TM], axor[TM];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-        }
-        const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
-        int abase[TM], axor[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const bool ok = (vmask[tm] >> sl) & 1u;
-            const int ar = ok ? lrow[tm] + h + off : ZROW;
-            abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
-        }
-        uint4 afr[2][TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1, g = sl * KS + ks;
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+            for (int tm = 0; tm < TM; ++tm) {
+                const bool ok = (vmask[tm] >> sl) & 1u;
+                const int ar = ok ? lrow[tm] + h + off : ZROW;
+                abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
             }
-            bf16x8 bf[TN];
+            uint4 afr[2][TM];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[g % RING][tn]);
+            for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
-            if (g + RING < 18 * KS) {               // refill this ring slot with k-step g + RING (possibly of the next tap / conv)
-                const int g2 = g + RING, sl2 = g2 / KS, ks2 = g2 % KS;
-                const uint4* wsrc = (sl2 < 9 ? w1 : w2) + (size_t)(sl2 % 9) * BSL + ks2 * 2 * BN;
+                    for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                }
+                bf16x8 bf[TN];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bfr[g % RING][tn] = wsrc[tn * 32];
+                for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
+                // refill this ring slot with k-step ks + RING (of this tap, or of the next one)
+                if (ks + RING < KS) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
+                } else {                            // the last tap re-reads its own slice: harmless, keeps the loop branch-free
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(nsl, ks + RING - KS, tn);
+                }
             }
+            RB_STAMP(3 + sl);
         }
-        RB_STAMP(3 + sl);
-        if (sl == 8) {
+        if (conv == 0) {
             __syncthreads();                        // every wave is done with the x image
             // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
             bf16_t* Hs = reinterpret_cast<bf16_t*>(As);

@@ -335,7 +335,8 @@ struct ResNetEvaluator : Evaluator {
     std::map<std::string, bf16_t*> b16;             // device bf16 conv weights by name
     bf16_t *X = nullptr, *Aa = nullptr, *Hh = nullptr, *X2 = nullptr;
     bool fused = true;
-    int stamp_calls = 0;
+    int stamp_calls = 0, n_cus = 256;
+    unsigned* cu_slots = nullptr;
     bf16_t* stem_frag = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
@@ -361,12 +362,15 @@ struct ResNetEvaluator : Evaluator {
             float* d = dalloc<float>(numel); if (!d) { *err = "hipMalloc"; return false; }
             hipMemcpy(d, g->data, numel * 4, hipMemcpyHostToDevice); f32[name] = d; return true;
         };
+        // a block's conv1 / conv2 weights share one allocation (conv2 right behind conv1): k_resblock3 walks them as 18 slices
+        bool pair_first = false; bf16_t* pair_next = nullptr;
         auto up_b16 = [&](const std::string& name, int64_t numel) -> bool {      // conv weights [9][cout][cin] -> fragment order
             const gaz_tensor* g = need(name, numel); if (!g) return false;
             std::vector<bf16_t> h(numel);
             const int cin = 128, cout = (int)(numel / (9 * cin));
             arrange_conv_weights(g->data, cout, cin, h.data(), f2bf_host);
-            bf16_t* d = dalloc<bf16_t>(numel); if (!d) { *err = "hipMalloc"; return false; }
+            bf16_t* d = pair_next ? pair_next : dalloc<bf16_t>(numel * (pair_first ? 2 : 1)); if (!d) { *err = "hipMalloc"; return false; }
+            pair_next = pair_first ? d + numel : nullptr; pair_first = false;
             hipMemcpy(d, h.data(), numel * 2, hipMemcpyHostToDevice); b16[name] = d; return true;
         };
         const int Fc = filters, F = HW * 8;
@@ -388,6 +392,7 @@ struct ResNetEvaluator : Evaluator {
         }
         for (int i = 0; i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i);
+            pair_first = true;
             if (!up_f32(b + ".bn1.scale", Fc) || !up_f32(b + ".bn1.shift", Fc) || !up_b16(b + ".conv1.w", 9LL * Fc * Fc) ||
                 !up_f32(b + ".conv1.scale", Fc) || !up_f32(b + ".conv1.shift", Fc) || !up_b16(b + ".conv2.w", 9LL * Fc * Fc) ||
                 !up_f32(b + ".conv2.bias", Fc)) return 1;
@@ -443,6 +448,8 @@ struct ResNetEvaluator : Evaluator {
             ResBlockArgs r; r.xin = cur; r.xout = cur == X ? X2 : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
             r.s1 = f32[b + ".bn1.scale"]; r.t1 = f32[b + ".bn1.shift"]; r.s2 = f32[b + ".conv1.scale"]; r.t2 = f32[b + ".conv1.shift"];
             r.b2 = f32[b + ".conv2.bias"]; r.M = M; r.H = H; r.W = W; r.stamps = nullptr;
+            static const int stagger_us10 = getenv("GAZ_RB_STAGGER") ? atoi(getenv("GAZ_RB_STAGGER")) : 0;    // tenths of a microsecond
+            r.cu_slots = stagger_us10 > 0 ? cu_slots : nullptr; r.stagger_wgs = 2 * n_cus; r.stagger_ticks = stagger_us10 * 10;
             static const int rbv = getenv("GAZ_RB") ? atoi(getenv("GAZ_RB")) : 3;
             static const int rb_tm = getenv("GAZ_RB_TM") ? atoi(getenv("GAZ_RB_TM")) : 0;
             static const int rb_ring = getenv("GAZ_RB_RING") ? atoi(getenv("GAZ_RB_RING")) : 8;
@@ -463,7 +470,8 @@ struct ResNetEvaluator : Evaluator {
             const bool stamp = stamp_path && i == 1 && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * RB_STAMPS * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * RB_STAMPS * 8, s); }
             if (rbv == 3) {
-                if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+                if (tm == 2 && rb_ring == 4) hipLaunchKernelGGL((k_resblock3<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+                else if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
                 else if (tm == 3 && rb_ring == 8) hipLaunchKernelGGL((k_resblock3<3, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
                 else if (tm == 3) hipLaunchKernelGGL((k_resblock3<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
                 else hipLaunchKernelGGL((k_resblock3<4, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
@@ -728,12 +736,17 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->logits = cfg.policy_is_logits;
     const size_t M = (size_t)cfg.n_games * e->HW;
     e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
+    e->cu_slots = e->dalloc<unsigned>(8 * 256);
+    if (e->cu_slots) hipMemset(e->cu_slots, 0, 8 * 256 * sizeof(unsigned));
+    { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
     e->pd1 = e->dalloc<float>((size_t)cfg.n_games * 128); e->vd1 = e->dalloc<float>((size_t)cfg.n_games * 128);
     if (!e->X || !e->Aa || !e->Hh || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1) { *err = "hipMalloc failed"; delete e; return nullptr; }
     // dynamic LDS above 64 KB needs the attribute
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_resblock2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
