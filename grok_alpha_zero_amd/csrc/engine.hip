@@ -17,16 +17,17 @@ static std::string g_create_error;
     do { hipError_t _e = (expr); if (_e != hipSuccess) { return fail(std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
 
 // ------------------------------------------------------------------------------------------ kernels
-template <class G> GAZ_KERNEL k_wave(DevParams<G> E) {
+// one wavefront per game of [g0, g1)
+template <class G> GAZ_KERNEL k_wave(DevParams<G> E, int g0, int g1) {
     GAZ_SHARED Scratch<G> S;
-    const int g = block_id();
-    if (g < E.n_games) game_step<G>(E, g, S);
+    const int g = g0 + block_id();
+    if (g < g1) game_step<G>(E, g, S);
 }
 
-template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E) {
+template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) {
     GAZ_SHARED Scratch<G> S;
-    const int g = block_id();
-    if (g < E.n_games) g_game_step<G>(E, g, S);
+    const int g = g0 + block_id();
+    if (g < g1) g_game_step<G>(E, g, S);
 }
 
 template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
@@ -158,7 +159,8 @@ template <class G> struct EngineT : gaz_engine {
     int32_t* dCount = nullptr; int32_t* dMoves = nullptr; int32_t* dSlots = nullptr;
     uint32_t ring_consumed = 0;
     bool timing = false;
-    std::vector<hipEvent_t> ev;      // triples: before tree, after tree, after eval
+    std::vector<hipEvent_t> ev;      // every timing event (owned)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_eval;   // brackets around tree steps / evaluator passes
     int64_t n_waves_total = 0;
     std::vector<void*> allocs;
 
@@ -174,6 +176,7 @@ template <class G> struct EngineT : gaz_engine {
         delete eval;
         for (void* p : allocs) hipFree(p);
         for (hipEvent_t e : ev) hipEventDestroy(e);
+        if (pipeline_ready) { hipStreamSynchronize(tstream); for (auto& p : pe) for (hipEvent_t e : p) hipEventDestroy(e); hipStreamDestroy(tstream); }
         hipStreamDestroy(stream);
     }
 
@@ -278,10 +281,11 @@ template <class G> struct EngineT : gaz_engine {
 
     hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
 
-    void launch_wave() {
-        if (cfg.search == GAZ_SEARCH_GUMBEL) GAZ_LAUNCH(k_wave_gumbel<G>, E.n_games, WAVE, stream, E);
-        else GAZ_LAUNCH(k_wave<G>, E.n_games, WAVE, stream, E);
+    void launch_wave(hipStream_t st, int g0, int g1) {
+        if (cfg.search == GAZ_SEARCH_GUMBEL) GAZ_LAUNCH(k_wave_gumbel<G>, g1 - g0, WAVE, st, E, g0, g1);
+        else GAZ_LAUNCH(k_wave<G>, g1 - g0, WAVE, st, E, g0, g1);
     }
+    void launch_wave() { launch_wave(stream, 0, E.n_games); }
 
     int one_wave(bool with_eval) {
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
@@ -289,9 +293,59 @@ template <class G> struct EngineT : gaz_engine {
         launch_wave();
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
-        if (timing) hipEventRecord(e2, stream);
+        if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); }
         n_waves_total++;
         return 0;
+    }
+
+    // ---- two-half pipeline (free-running self-play only).  The games are split in two halves A | B; `stream` carries the
+    // evaluator passes eval(A), eval(B), eval(A), ... back to back, `tstream` the tree steps.  tree(B, k) runs while eval(A, k)
+    // does, tree(A, k + 1) while eval(B, k) does: the tree kernel (one latency-bound wavefront per game, a tenth of the step)
+    // disappears behind the MFMA kernels.  Per-game results do not depend on the split: rows of a batch are independent.
+    hipStream_t tstream = 0;
+    hipEvent_t pe[2][4] = {};                       // [parity][tree A done, tree B done, eval A done, eval B done]
+    bool pipeline_ready = false;
+    bool can_pipeline() {
+        // opt-in (GAZ_PIPELINE=1): measured on Connect4 / 4096 games it LOSES 13 % (27.5k vs 31.5k positions/s) — the half-batch
+        // evaluator passes pay the launch gaps and tails of ten small kernels twice, more than the hidden tree step is worth
+        static const bool on = getenv("GAZ_PIPELINE") && atoi(getenv("GAZ_PIPELINE")) != 0;
+        if (!on || E.sync_moves || !eval || !eval->supports_row_base() || E.n_games < 1024) return false;
+        if (!pipeline_ready) {
+            if (hipStreamCreate(&tstream) != hipSuccess) return false;
+            for (int p = 0; p < 2; ++p) for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&pe[p][i], hipEventDisableTiming);
+            pipeline_ready = true;
+        }
+        return true;
+    }
+    int run_waves_pipelined(int n) {
+        const int gA = E.n_games / 2, gB = E.n_games;
+        const int in_row = G::HW * G::C;
+        hipEvent_t e_in = pe[0][0];                 // tstream starts after everything already queued on `stream`
+        hipEventRecord(e_in, stream); hipStreamWaitEvent(tstream, e_in, 0);
+        for (int k = 0; k < n; ++k) {
+            hipEvent_t* ce = pe[k & 1]; hipEvent_t* le = pe[(k & 1) ^ 1];
+            for (int half = 0; half < 2; ++half) {
+                const int g0 = half ? gA : 0, g1 = half ? gB : gA;
+                if (k > 0) hipStreamWaitEvent(tstream, le[2 + half], 0);            // this half's previous evaluation
+                hipEvent_t t0 = 0, t1 = 0;
+                if (timing) { t0 = new_event(); t1 = new_event(); hipEventRecord(t0, tstream); }
+                launch_wave(tstream, g0, g1);
+                if (timing) { hipEventRecord(t1, tstream); ev_tree.push_back({t0, t1}); }
+                hipEventRecord(ce[half], tstream);
+            }
+            for (int half = 0; half < 2; ++half) {
+                const int g0 = half ? gA : 0, g1 = half ? gB : gA;
+                hipStreamWaitEvent(stream, ce[half], 0);
+                hipEvent_t v0 = 0, v1 = 0;
+                if (timing) { v0 = new_event(); v1 = new_event(); hipEventRecord(v0, stream); }
+                eval->forward(stream, E.nn_in + (size_t)g0 * in_row, E.nn_policy + (size_t)g0 * G::A, E.nn_value + g0, g1 - g0, timing, g0);
+                if (timing) { hipEventRecord(v1, stream); ev_eval.push_back({v0, v1}); }
+                hipEventRecord(ce[2 + half], stream);
+            }
+            n_waves_total++;
+        }
+        HIP_OK(hipGetLastError());
+        return 0;                                   // `stream` ends with eval(B, n - 1): every tree step is ordered before it
     }
 
     int counts(int32_t out[8]) {
@@ -354,6 +408,7 @@ template <class G> struct EngineT : gaz_engine {
     int run_waves(int n) override {
         if (!eval) return fail("run_waves needs a built-in evaluator");
         if (!eval->ready()) return fail("run_waves: evaluator weights not loaded (gaz_engine_load_weights)");
+        if (can_pipeline()) return run_waves_pipelined(n);
         for (int i = 0; i < n; ++i) one_wave(true);
         HIP_OK(hipGetLastError());
         return 0;
@@ -442,7 +497,7 @@ template <class G> struct EngineT : gaz_engine {
     int timing_reset(int enable) override {
         HIP_OK(hipStreamSynchronize(stream));
         for (hipEvent_t e : ev) hipEventDestroy(e);
-        ev.clear(); n_waves_total = 0; timing = enable != 0;
+        ev.clear(); ev_tree.clear(); ev_eval.clear(); n_waves_total = 0; timing = enable != 0;
         if (eval) eval->timing_reset();
         return 0;
     }
@@ -460,7 +515,9 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
     int dominant(char* name, int cap, double* flops) override {
-        double f = 0; const char* k = eval ? eval->dominant_kernel(E.n_games, &f) : "";
+        // positions per evaluator launch: the pipelined run evaluates the two halves of the games separately
+        const int n_launch = can_pipeline() ? E.n_games / 2 : E.n_games;
+        double f = 0; const char* k = eval ? eval->dominant_kernel(n_launch, &f) : "";
         if (name && cap > 0) { strncpy(name, k, cap - 1); name[cap - 1] = 0; }
         if (flops) *flops = f;
         return 0;
@@ -468,11 +525,8 @@ template <class G> struct EngineT : gaz_engine {
     int timing_get(double* ms_tree, double* ms_eval, double* ms_dom, int64_t* n_dom, int64_t* n_waves) override {
         HIP_OK(hipStreamSynchronize(stream));
         double t = 0, e = 0;
-        for (size_t i = 0; i + 2 < ev.size(); i += 3) {
-            float a = 0, b = 0;
-            hipEventElapsedTime(&a, ev[i], ev[i + 1]); hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]);
-            t += a; e += b;
-        }
+        for (auto& pr : ev_tree) { float a = 0; hipEventElapsedTime(&a, pr.first, pr.second); t += a; }
+        for (auto& pr : ev_eval) { float b = 0; hipEventElapsedTime(&b, pr.first, pr.second); e += b; }
         if (ms_tree) *ms_tree = t; if (ms_eval) *ms_eval = e;
         double d = 0; int64_t nd = 0;
         if (eval) eval->timing_get(&d, &nd);

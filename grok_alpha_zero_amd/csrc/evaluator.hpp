@@ -15,7 +15,10 @@ namespace gaz {
 struct Evaluator {
     virtual ~Evaluator() {}
     virtual int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) { (void)t; (void)n; (void)s; (void)err; return 0; }
-    virtual void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) = 0;
+    // p0: first row of the evaluator's internal activation buffers this call may use (rows [p0, p0 + n)); two calls on
+    // disjoint row ranges may be in flight on different streams (the engine pipelines two halves of the games)
+    virtual void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) = 0;
+    virtual bool supports_row_base() const { return false; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
@@ -54,7 +57,7 @@ template <int UNUSED> GAZ_KERNEL k_hash_eval(const int8_t* in, float* policy, fl
 struct HashEvaluator : Evaluator {
     int row_bytes, A; uint32_t salt;
     HashEvaluator(int rb, int a, uint32_t s) : row_bytes(rb), A(a), salt(s) {}
-    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool) override {
+    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool, int = 0) override {
         const int total = n * (A + 1);
 #ifdef GAZ_HOST_EMU
         GAZ_LAUNCH(k_hash_eval<0>, total, 1, s, in, policy, value, n, row_bytes, A, salt);

@@ -425,9 +425,15 @@ struct ResNetEvaluator : Evaluator {
         n_trunk_launches++;
     }
 
-    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) override {
+    bool supports_row_base() const override { return true; }
+    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         if (!loaded) return;                        // engine_create without weights: outputs stay as they are
         const int M = n * HW;
+        // activation / feature buffers of rows [p0, p0 + n)
+        bf16_t* const X = this->X + (size_t)p0 * HW * 128; bf16_t* const X2 = this->X2 + (size_t)p0 * HW * 128;
+        bf16_t* const Aa = this->Aa + (size_t)p0 * HW * 128; bf16_t* const Hh = this->Hh + (size_t)p0 * HW * 128;
+        float* const pfeat = this->pfeat + (size_t)p0 * HW * 8; float* const vfeat = this->vfeat + (size_t)p0 * HW * 8;
+        float* const pd1 = this->pd1 + (size_t)p0 * 128; float* const vd1 = this->vd1 + (size_t)p0 * 128;
         StemArgs st; st.in = in; st.w = f32["stem.w"]; st.scale = f32["stem.scale"]; st.shift = f32["stem.shift"];
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
         st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
@@ -530,7 +536,7 @@ struct ResNetEvaluator : Evaluator {
     const char* dominant_kernel(int n, double* flops) override {
         const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
         *flops = fused ? 2 * conv : conv;
-        return fused ? "k_resblock (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
+        return fused ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                      : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
 };
@@ -633,7 +639,7 @@ struct GenericEvaluator : Evaluator {
     }
     float* g(const std::string& k) { return f32[k]; }
 
-    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing) override {
+    void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int = 0) override {
         if (!loaded) return;
         const int M = n * HW, SC = gomoku ? 256 : 128;
         StemGenArgs st; memset(&st, 0, sizeof(st));

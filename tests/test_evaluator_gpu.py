@@ -138,3 +138,40 @@ def test_gomoku_tictactoe_evaluators_match_torch_fp32(game, blocks, n):
     assert dv.max() <= 0.15 and dv.mean() <= 2e-2, (dv.max(), dv.mean())
     assert (pol.argmax(1) == p_ref.numpy().argmax(1)).mean() >= 0.9
     eng.close()
+
+
+_PIPE_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+from grok_alpha_zero_amd.net import Connect4Net
+net = Connect4Net(2, seed=3).eval()
+eng = SelfPlayEngine("Connect4", 1024, 24, 12, 4, 3, 2.5, 0.5, seed=11, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=4096)
+eng.load_weights(net.export_engine_weights())
+eng.run_waves(450)
+eng.synchronize()
+recs = eng.drain_finished(4096)
+h = hashlib.sha256()
+for r in sorted(recs, key=lambda r: (r["slot"], r["game_seq"])):
+    for k in ("slot", "game_seq", "winner", "T"):
+        h.update(np.int64(r[k]).tobytes())
+    for k in ("actions", "root_N", "root_W", "policies", "q"):
+        h.update(np.ascontiguousarray(r[k]).tobytes())
+print(len(recs), h.hexdigest())
+"""
+
+
+def test_two_half_pipeline_gives_identical_games(tmp_path):
+    """GAZ_PIPELINE=1 (tree step of one half of the games behind the evaluator pass of the other) must not change a single
+    game: same finished records, bit for bit.  The switch is read once per process, hence the subprocesses."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "pipe.py"; script.write_text(_PIPE_SCRIPT)
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, GAZ_PIPELINE=flag)
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert int(outs[0].split()[0]) > 200                   # games did finish
+    assert outs[0] == outs[1]
