@@ -56,6 +56,56 @@ __global__ __launch_bounds__(256) void k_stem_generic(StemGenArgs a) {
         *reinterpret_cast<uint4*>(a.out2 + o) = make_uint4(pack_bf16(w2[0], w2[1]), pack_bf16(w2[2], w2[3]), pack_bf16(w2[4], w2[5]), pack_bf16(w2[6], w2[7]));
 }
 
+// ---- head convolution 32 -> COUT (8 | 4) with a flat fp32 output: one thread per cell computes all COUT outputs, the weights
+// sit in LDS as [tap][cin][cout] (every lane reads the same address: broadcast), the 32 input channels of a tap arrive as
+// four 16-byte loads.  out[b][cell * COUT + co] = act((acc + bias[co]) * fs[f] + ft[f])  (Gomoku p.c2 3x3 / v.c2 1x1).
+struct ConvSmallArgs { const bf16_t* in; const float* w; const float* bias; float* flat; const float* fs; const float* ft; int act; int M, H, W; };
+template <int COUT, int K>
+__global__ __launch_bounds__(256) void k_conv_small(ConvSmallArgs a) {
+    constexpr int CIN = 32, T = K * K;
+    __shared__ float wl[T * CIN * COUT];
+    for (int i = threadIdx.x; i < T * CIN * COUT; i += 256) {        // [tap][cout][cin] -> [tap][cin][cout]
+        const int tap = i / (CIN * COUT), rem = i % (CIN * COUT), co = rem / CIN, c = rem % CIN;
+        wl[(tap * CIN + c) * COUT + co] = a.w[i];
+    }
+    __syncthreads();
+    const long gr = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gr >= a.M) return;
+    const int HW = a.H * a.W, cell = (int)((unsigned long)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W, r = K / 2;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+        const int dy = tap / K - r, dx = tap % K - r;
+        if ((unsigned)(y + dy) >= (unsigned)a.H || (unsigned)(x + dx) >= (unsigned)a.W) continue;
+        const uint4* px = reinterpret_cast<const uint4*>(a.in + (gr + (long)dy * a.W + dx) * CIN);
+        uint4 pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[q] = px[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned pw[4] = {pv[q].x, pv[q].y, pv[q].z, pv[q].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = (j & 1) ? __uint_as_float(pw[j >> 1] & 0xFFFF0000u) : __uint_as_float(pw[j >> 1] << 16);
+                const float* wr = &wl[(tap * CIN + q * 8 + j) * COUT];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] += xv * wr[co];
+            }
+        }
+    }
+    const long b = gr / HW;
+    float* o = a.flat + (size_t)b * HW * COUT + (size_t)cell * COUT;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float v = acc[co] + (a.bias ? a.bias[co] : 0.0f);
+        const int f = cell * COUT + co;
+        if (a.fs) v = v * a.fs[f] + a.ft[f];
+        o[co] = apply_act(v, a.act);
+    }
+}
+
 // ---- direct convolution for layers with few channels: in bf16 [M][CIN], w f32 [K*K][COUT][CIN], one thread per (cell, cout)
 struct ConvDirectArgs {
     const bf16_t* in; const float* w;

@@ -31,6 +31,25 @@ static bf16_t f2bf_host(float f) {
     return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// k_resblock3 launch: tile height 64 * TM with the least (rounds of 2 workgroups x n_cus) x TM, ties to the taller tile
+static int rb3_pick_tm(int M, int W, int n_cus) {
+    int tm = 3; double best = 1e30;
+    for (int c = 2; c <= 4; ++c) {
+        const int bm = 64 * c - 2 * (W + 1); const long nt = (M + bm - 1) / bm;
+        const double cost = (double)((nt + 2 * n_cus - 1) / (2 * n_cus)) * c;
+        if (cost <= best) { best = cost; tm = c; }
+    }
+    return tm;
+}
+static void rb3_launch(hipStream_t s, const ResBlockArgs& r, int tm, int ring) {
+    const int bmo = 64 * tm - 2 * (r.W + 1), nwg = (r.M + bmo - 1) / bmo;
+    if (tm == 2 && ring == 4) hipLaunchKernelGGL((k_resblock3<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+    else if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+    else if (tm == 3 && ring == 4) hipLaunchKernelGGL((k_resblock3<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+    else if (tm == 3) hipLaunchKernelGGL((k_resblock3<3, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+    else hipLaunchKernelGGL((k_resblock3<4, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
+}
+
 // ---- stem: Conv3x3(C_in = 4, int8 planes) -> 128, BN, exact GELU; second output relu(bn1_0(x))
 struct StemArgs {
     const int8_t* in;        // [B][HW][4]
@@ -92,7 +111,11 @@ __global__ __launch_bounds__(256) void k_stem(StemArgs a) {
 // share the activation operand (6 k-steps), which keeps ~16 mantissa bits.  One wave = one 32-cell tile x all 128
 // channels; each lane ends up with 4 consecutive channels of its own cell per accumulator quad -> 8-byte stores.
 // GELU is x * Phi(x) with Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8, output is bf16).
-struct StemMArgs { const int8_t* in; const uint4* wfrag; const float* shift; bf16_t* out; int M, H, W, tiles_per_wave; };
+struct StemMArgs {
+    const int8_t* in; const uint4* wfrag; const float* shift; bf16_t* out;
+    const float* scaleB; const float* shiftB; bf16_t* out2;      // OUT2: second output relu(out * scaleB + shiftB)
+    int M, H, W, tiles_per_wave;
+};
 
 __device__ __forceinline__ float gelu_as(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
@@ -106,69 +129,159 @@ __device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two
     return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
 }
 
+// CIN input planes (2: Gomoku, 4: Connect4), COUT channels, k = tap * CIN + plane padded to KST k-steps of 16; operand
+// k-steps [0, KST) carry the hi halves of the weights, [KST, 2 KST) the lo halves, against the same activations.
+template <int CIN> constexpr int stem_ksteps() { return (9 * CIN + 15) / 16; }
+template <int CIN, int COUT, bool GELU, bool OUT2>
 __global__ __launch_bounds__(256) void k_stem_mfma(StemMArgs a) {
-    __shared__ uint4 wl[6 * 2 * 128];              // [k-step (3 hi + 3 lo)][k-half][channel] x 8 bf16
-    __shared__ float sh[128];
+    constexpr int KST = stem_ksteps<CIN>(), TPL = 8 / CIN, NT = COUT / 32;
+    __shared__ uint4 wl[2 * KST * 2 * COUT];       // [k-step (KST hi + KST lo)][k-half][channel] x 8 bf16
+    __shared__ float sh[COUT]; __shared__ float sBl[OUT2 ? COUT : 1]; __shared__ float tBl[OUT2 ? COUT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     {
-        uint4 wv[6];
+        constexpr int NW = 2 * KST * 2 * COUT / 256;
+        uint4 wv[NW];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) wv[c] = a.wfrag[tid + 256 * c];
+        for (int c = 0; c < NW; ++c) wv[c] = a.wfrag[tid + 256 * c];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) wl[tid + 256 * c] = wv[c];
+        for (int c = 0; c < NW; ++c) wl[tid + 256 * c] = wv[c];
     }
-    if (tid < 128) sh[tid] = a.shift[tid];
+    for (int i = tid; i < COUT; i += 256) { sh[i] = a.shift[i]; if (OUT2) { sBl[i] = a.scaleB[i]; tBl[i] = a.shiftB[i]; } }
     __syncthreads();
-    const int* in32 = reinterpret_cast<const int*>(a.in);
     const int HW = a.H * a.W;
     for (int t = 0; t < a.tiles_per_wave; ++t) {
         const long tile = ((long)blockIdx.x * 4 + wave) * a.tiles_per_wave + t;
         if (tile * 32 >= a.M) break;               // wave-uniform
         const long gr = tile * 32 + l31;
         const bool rok = gr < a.M;
-        const int cell = (int)(gr % HW), y = cell / a.W, x = cell % a.W;
-        uint4 bfr[3];
+        const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+        uint4 bfr[KST];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            unsigned d[4];
+        for (int ks = 0; ks < KST; ++ks) {
+            int pl[8];                             // the 8 activations of this lane: taps ks * 16 / CIN + lhi * TPL + 0.., CIN planes each
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int tap = ks * 4 + lhi * 2 + h;
+            for (int h = 0; h < TPL; ++h) {
+                const int tap = ks * (16 / CIN) + lhi * TPL + h;
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 int packed = 0;
-                if (rok && tap < 9 && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W)
-                    packed = in32[gr + dy * a.W + dx];
-                d[2 * h] = s8x2_to_bf16x2((int)(int8_t)(packed & 0xFF), (int)(int8_t)((packed >> 8) & 0xFF));
-                d[2 * h + 1] = s8x2_to_bf16x2((int)(int8_t)((packed >> 16) & 0xFF), packed >> 24);
-            }
-            bfr[ks] = make_uint4(d[0], d[1], d[2], d[3]);
-        }
-        f32x16 acc[4];
+                if (rok && tap < 9 && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) {
+                    if (CIN == 4) packed = reinterpret_cast<const int*>(a.in)[gr + dy * a.W + dx];
+                    else packed = reinterpret_cast<const unsigned short*>(a.in)[gr + dy * a.W + dx];
+                }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+                for (int c = 0; c < CIN; ++c) pl[h * CIN + c] = (int)(int8_t)((packed >> (8 * c)) & 0xFF);
+            }
+            bfr[ks] = make_uint4(s8x2_to_bf16x2(pl[0], pl[1]), s8x2_to_bf16x2(pl[2], pl[3]), s8x2_to_bf16x2(pl[4], pl[5]), s8x2_to_bf16x2(pl[6], pl[7]));
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
 #pragma unroll
-        for (int ks6 = 0; ks6 < 6; ++ks6) {
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&bfr[ks6 % 3]);
+        for (int ks2 = 0; ks2 < 2 * KST; ++ks2) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&bfr[ks2 % KST]);
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                const uint4 av = wl[(ks6 * 2 + lhi) * 128 + tm * 32 + l31];
+            for (int tm = 0; tm < NT; ++tm) {
+                const uint4 av = wl[(ks2 * 2 + lhi) * COUT + tm * 32 + l31];
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&av), bf, acc[tm], 0, 0, 0);
             }
         }
         if (!rok) continue;
         // D rows (channels) of lane: (r & 3) + 8 * (r >> 2) + 4 * lhi, column (cell) = l31
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < NT; ++tm)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int ch0 = tm * 32 + rg * 8 + lhi * 4;
-                const float4 s4 = *reinterpret_cast<const float4*>(&sh[ch0]);
-                const float v0 = gelu_as(acc[tm][rg * 4 + 0] + s4.x), v1 = gelu_as(acc[tm][rg * 4 + 1] + s4.y);
-                const float v2 = gelu_as(acc[tm][rg * 4 + 2] + s4.z), v3 = gelu_as(acc[tm][rg * 4 + 3] + s4.w);
-                *reinterpret_cast<uint2*>(a.out + (size_t)gr * 128 + ch0) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = acc[tm][rg * 4 + q] + sh[ch0 + q];
+                    v[q] = GELU ? gelu_as(u) : fmaxf(u, 0.0f);
+                }
+                *reinterpret_cast<uint2*>(a.out + (size_t)gr * COUT + ch0) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                if (OUT2) {
+                    float w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = fmaxf(v[q] * sBl[ch0 + q] + tBl[ch0 + q], 0.0f);
+                    *reinterpret_cast<uint2*>(a.out2 + (size_t)gr * COUT + ch0) = make_uint2(pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]));
+                }
             }
+    }
+}
+
+// host: [9][COUT][CIN] fp32 stem weights (BN scale folded in) -> the operand layout above
+static std::vector<bf16_t> stem_fragments(const float* w, const float* sc, int CIN, int COUT) {
+    const int KST = (9 * CIN + 15) / 16;
+    std::vector<bf16_t> h((size_t)2 * KST * 2 * COUT * 8, 0);
+    for (int ks2 = 0; ks2 < 2 * KST; ++ks2) for (int half = 0; half < 2; ++half) for (int ch = 0; ch < COUT; ++ch) for (int j = 0; j < 8; ++j) {
+        const int k = (ks2 % KST) * 16 + half * 8 + j;
+        if (k >= 9 * CIN) continue;
+        const float wv = w[((k / CIN) * COUT + ch) * CIN + (k % CIN)] * sc[ch];
+        const bf16_t hi = f2bf_host(wv);
+        unsigned hu = (unsigned)hi << 16; float hf; memcpy(&hf, &hu, 4);
+        h[(((size_t)ks2 * 2 + half) * COUT + ch) * 8 + j] = ks2 < KST ? hi : f2bf_host(wv - hf);
+    }
+    return h;
+}
+
+// ---- Dense(K -> N) + optional per-output scale / shift + activation on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+// Block = 32 positions x 128 outputs (4 waves x 32 columns), blockIdx.y = 128-output group; K in chunks staged in LDS.
+struct DenseMArgs { const float* in; const float* w; const float* scale; const float* shift; float* out; int B, K, N, act; };
+constexpr int DM_KC = 448;                         // 32 x 449 floats = 57 KB of LDS per chunk
+__global__ __launch_bounds__(256) void k_dense_mfma(DenseMArgs a) {
+    extern __shared__ float fl[];                  // [32][DM_KC + 1]
+    constexpr int G = 8, D = 4, FP = DM_KC + 1;
+    const int b0 = blockIdx.x * 32, K = a.K, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int n = blockIdx.y * 128 + wave * 32 + l31, nc = n < N ? n : N - 1;          // clamped column: loads stay in bounds
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += DM_KC) {
+        const int kc = K - k0 < DM_KC ? K - k0 : DM_KC, NG = (kc + 2 * G - 1) / (2 * G);
+        __syncthreads();                           // the previous chunk's readers are done
+        for (int p = threadIdx.x >> 6; p < 32; p += 4) {
+            const size_t rb = (size_t)min(b0 + p, a.B - 1) * K + k0;
+            const bool rok = b0 + p < a.B;
+            for (int kb = threadIdx.x & 63; kb < NG * 2 * G; kb += 64 * 7) {
+                float v[7];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) v[c] = a.in[rb + min(kb + 64 * c, kc - 1)];
+#pragma unroll
+                for (int c = 0; c < 7; ++c) { const int k = kb + 64 * c; if (k < NG * 2 * G) fl[p * FP + k] = (rok && k < kc) ? v[c] : 0.0f; }
+            }
+        }
+        __syncthreads();
+        float bq[D][G];
+        auto ldg = [&](int g, float* dst) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) { const int k = min(g * 2 * G + 2 * j + lhi, kc - 1); dst[j] = a.w[(size_t)(k0 + k) * N + nc]; }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) ldg(d, bq[d]);
+        for (int g0 = 0; g0 < NG; g0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int g = g0 + d;
+                ldg(g + D - 1, bq[(d + D - 1) % D]);
+                if (g < NG) {                       // wave-uniform
+                    float av[G];
+#pragma unroll
+                    for (int j = 0; j < G; ++j) av[j] = fl[l31 * FP + g * 2 * G + 2 * j + lhi];
+#pragma unroll
+                    for (int j = 0; j < G; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bq[d][j], acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (n >= N) return;
+    const float s = a.scale ? a.scale[n] : 1.0f, t = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (b0 + row < a.B) a.out[(size_t)(b0 + row) * N + n] = apply_act(acc[r] * s + t, a.act);
     }
 }
 
@@ -375,18 +488,9 @@ struct ResNetEvaluator : Evaluator {
         };
         const int Fc = filters, F = HW * 8;
         if (!up_f32("stem.w", 9 * 128 * C) || !up_f32("stem.scale", 128) || !up_f32("stem.shift", 128)) return 1;
-        {   // MFMA stem operand: [6 k-steps (hi, hi, hi, lo, lo, lo)][k-half][channel][8], BN scale folded into the weights
+        {   // MFMA stem operand, BN scale folded into the weights
             if (C != 4) { *err = "stem expects 4 input planes"; return 1; }
-            const float* w = by["stem.w"]->data; const float* sc = by["stem.scale"]->data;
-            std::vector<bf16_t> h(6 * 2 * 128 * 8, 0);
-            for (int ks6 = 0; ks6 < 6; ++ks6) for (int half = 0; half < 2; ++half) for (int ch = 0; ch < 128; ++ch) for (int j = 0; j < 8; ++j) {
-                const int k = (ks6 % 3) * 16 + half * 8 + j;
-                if (k >= 36) continue;
-                const float wv = w[((k / 4) * 128 + ch) * 4 + (k % 4)] * sc[ch];
-                const bf16_t hi = f2bf_host(wv);
-                unsigned hu = (unsigned)hi << 16; float hf; memcpy(&hf, &hu, 4);
-                h[(((size_t)ks6 * 2 + half) * 128 + ch) * 8 + j] = ks6 < 3 ? hi : f2bf_host(wv - hf);
-            }
+            const std::vector<bf16_t> h = stem_fragments(by["stem.w"]->data, by["stem.scale"]->data, 4, 128);
             stem_frag = dalloc<bf16_t>(h.size()); if (!stem_frag) { *err = "hipMalloc"; return 1; }
             hipMemcpy(stem_frag, h.data(), h.size() * 2, hipMemcpyHostToDevice);
         }
@@ -438,11 +542,11 @@ struct ResNetEvaluator : Evaluator {
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
         st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
         if (fused) {
-            StemMArgs sm; sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = f32["stem.shift"]; sm.out = X;
+            StemMArgs sm; memset(&sm, 0, sizeof(sm)); sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = f32["stem.shift"]; sm.out = X;
             sm.M = M; sm.H = H; sm.W = W;
             const int tiles = (M + 31) / 32;
             sm.tiles_per_wave = std::max(1, (tiles + 1343) / 2688);     // ~2.7k waves: ten per CU, each amortising the 24-KB weight stage
-            hipLaunchKernelGGL(k_stem_mfma, dim3((tiles + 4 * sm.tiles_per_wave - 1) / (4 * sm.tiles_per_wave)), dim3(256), 0, s, sm);
+            hipLaunchKernelGGL((k_stem_mfma<4, 128, true, false>), dim3((tiles + 4 * sm.tiles_per_wave - 1) / (4 * sm.tiles_per_wave)), dim3(256), 0, s, sm);
         } else {
             hipLaunchKernelGGL(k_stem, dim3((M + 63) / 64), dim3(256), 0, s, st);
         }
@@ -461,27 +565,19 @@ struct ResNetEvaluator : Evaluator {
             static const int rb_ring = getenv("GAZ_RB_RING") ? atoi(getenv("GAZ_RB_RING")) : 8;
             // k_resblock3: tile height 64 * TM; take the TM with the least (rounds of 512 workgroups) x (tile cost ~ TM)
             int tm = rb_tm;
-            if (rbv == 3 && tm == 0) {
-                double best = 1e30;
-                for (int c = 2; c <= 4; ++c) {
-                    const int bm = 64 * c - 2 * (W + 1); const long nt = (M + bm - 1) / bm;
-                    const double cost = (double)((nt + 511) / 512) * c;
-                    if (cost <= best) { best = cost; tm = c; }      // ties: the taller tile (less halo recompute)
-                }
-            }
-            const int bmo = (rbv == 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
+            if (rbv >= 3 && tm == 0) tm = rb3_pick_tm(M, W, n_cus);
+            const int bmo = (rbv >= 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
             const int nwg = (M + bmo - 1) / bmo;
             static const char* stamp_path = getenv("GAZ_RB_STAMPS");       // diagnostic: phase stamps of one launch -> file
             const bool stamp = stamp_path && i == 1 && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * RB_STAMPS * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * RB_STAMPS * 8, s); }
-            if (rbv == 3) {
-                if (tm == 2 && rb_ring == 4) hipLaunchKernelGGL((k_resblock3<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
-                else if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
-                else if (tm == 3 && rb_ring == 8) hipLaunchKernelGGL((k_resblock3<3, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
-                else if (tm == 3) hipLaunchKernelGGL((k_resblock3<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
-                else hipLaunchKernelGGL((k_resblock3<4, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
-            }
+            if (rbv == 4) {
+                if (tm == 2) hipLaunchKernelGGL((k_resblock4<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
+                else if (tm == 3 && rb_ring == 2) hipLaunchKernelGGL((k_resblock4<3, 2>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+                else if (tm == 3) hipLaunchKernelGGL((k_resblock4<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
+                else hipLaunchKernelGGL((k_resblock4<4, 2>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
+            } else if (rbv == 3) rb3_launch(s, r, tm, rb_ring);
             else if (rbv == 2) hipLaunchKernelGGL(k_resblock2, dim3(nwg), dim3(RB_THREADS), (size_t)CONV_AROWS_256 * 256, s, r);
             else hipLaunchKernelGGL(k_resblock, dim3(nwg), dim3(RB_THREADS), lds, s, r);
             if (stamp) {
@@ -551,6 +647,8 @@ struct GenericEvaluator : Evaluator {
     bf16_t *X0 = nullptr, *A0 = nullptr, *X = nullptr, *Aa = nullptr, *Hh = nullptr, *Va = nullptr, *PH = nullptr, *VH = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
     std::vector<hipEvent_t> tev; int trunk_convs = 0;
+    bool fused = true; int n_cus = 256, fused_blocks = 0;      // Gomoku blocks 1.. run as k_resblock3 (one kernel per block)
+    bf16_t* stem_frag = nullptr;
 
     ~GenericEvaluator() override { for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e); }
     template <class T> T* dalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n + 64) * sizeof(T)) != hipSuccess) return nullptr; allocs.push_back(p); return (T*)p; }
@@ -576,15 +674,32 @@ struct GenericEvaluator : Evaluator {
         hipMemcpy(d, h.data(), numel * 2, hipMemcpyHostToDevice); b16[name] = d; return true;
     }
 
+    // conv1 / conv2 of a 128 -> 128 block in ONE allocation (conv2 right behind conv1): k_resblock3 walks them as 18 slices
+    bool up_mfma_pair(const std::string& n1, const std::string& n2, int F_) {
+        const int64_t numel = 9LL * F_ * F_;
+        const gaz_tensor* g1 = need(n1, numel); const gaz_tensor* g2 = need(n2, numel); if (!g1 || !g2) return false;
+        std::vector<bf16_t> h(2 * numel);
+        arrange_conv_weights(g1->data, F_, F_, h.data(), f2bf_host, 9);
+        arrange_conv_weights(g2->data, F_, F_, h.data() + numel, f2bf_host, 9);
+        bf16_t* d = dalloc<bf16_t>(2 * numel); if (!d) { lerr = "hipMalloc"; return false; }
+        hipMemcpy(d, h.data(), 2 * numel * 2, hipMemcpyHostToDevice); b16[n1] = d; b16[n2] = d + numel; return true;
+    }
+
     int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) override {
         by.clear(); for (int i = 0; i < n; ++i) by[t[i].name] = &t[i];
         const int SC = gomoku ? 256 : 128, K = gomoku ? 3 : 5;
         bool ok = up("stem.w", (int64_t)K * K * SC * C) && up("stem.scale", SC) && up("stem.shift", SC);
+        if (ok && gomoku) {                         // MFMA stem operand (2 planes x 9 taps -> 256 channels), BN scale folded in
+            const std::vector<bf16_t> h = stem_fragments(by["stem.w"]->data, by["stem.scale"]->data, 2, 256);
+            stem_frag = dalloc<bf16_t>(h.size()); ok = stem_frag != nullptr;
+            if (ok) hipMemcpy(stem_frag, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        }
         for (int i = 0; ok && i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i); const int cin = i == 0 ? SC : F;
             ok = up(b + ".bn1.scale", cin) && up(b + ".bn1.shift", cin) && up(b + ".conv1.scale", F) && up(b + ".conv1.shift", F) && up(b + ".conv2.bias", F);
             if (!ok) break;
-            if (gomoku) ok = up_mfma(b + ".conv1.w", F, cin, 9) && up_mfma(b + ".conv2.w", F, F, 9);
+            if (gomoku && cin == F) ok = up_mfma_pair(b + ".conv1.w", b + ".conv2.w", F);
+            else if (gomoku) ok = up_mfma(b + ".conv1.w", F, cin, 9) && up_mfma(b + ".conv2.w", F, F, 9);
             else ok = up(b + ".conv1.w", 9LL * F * cin) && up(b + ".conv2.w", 9LL * F * F);
             if (ok && cin != F) ok = (gomoku ? up_mfma(b + ".proj.w", F, cin, 1) : up(b + ".proj.w", (int64_t)F * cin)) && up(b + ".proj.bias", F);
         }
@@ -635,6 +750,11 @@ struct GenericEvaluator : Evaluator {
         hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
     }
     void dense(hipStream_t s, const float* in, const std::string& w, const float* sc, const float* sh, float* out, int n, int K, int N, int act) {
+        if (gomoku && N >= 32) {                    // fp32 MFMA path
+            DenseMArgs d; d.in = in; d.w = f32[w]; d.scale = sc; d.shift = sh; d.out = out; d.B = n; d.K = K; d.N = N; d.act = act;
+            hipLaunchKernelGGL(k_dense_mfma, dim3((n + 31) / 32, (N + 127) / 128), dim3(256), (size_t)32 * (DM_KC + 1) * 4, s, d);
+            return;
+        }
         hipLaunchKernelGGL(k_dense, dim3((n + 7) / 8), dim3(128), (size_t)8 * K * 4, s, in, f32[w], sc, sh, out, n, K, N, act);
     }
     float* g(const std::string& k) { return f32[k]; }
@@ -645,16 +765,36 @@ struct GenericEvaluator : Evaluator {
         StemGenArgs st; memset(&st, 0, sizeof(st));
         st.in = in; st.w = g("stem.w"); st.scale = g("stem.scale"); st.shift = g("stem.shift"); st.scaleB = g("block0.bn1.scale"); st.shiftB = g("block0.bn1.shift");
         st.out1 = X0; st.out2 = A0; st.M = M; st.H = H; st.W = W; st.CIN = C; st.COUT = SC; st.K = gomoku ? 3 : 5; st.act = gomoku ? NACT_RELU : NACT_GELU;
-        hipLaunchKernelGGL(k_stem_generic, dim3((unsigned)(((long)M * (SC / 8) + 255) / 256)), dim3(256), 0, s, st);
+        if (gomoku) {
+            StemMArgs sm; memset(&sm, 0, sizeof(sm)); sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = g("stem.shift");
+            sm.out = X0; sm.scaleB = g("block0.bn1.scale"); sm.shiftB = g("block0.bn1.shift"); sm.out2 = A0; sm.M = M; sm.H = H; sm.W = W;
+            const int tiles = (M + 31) / 32;
+            sm.tiles_per_wave = std::max(1, (tiles + 1343) / 2688);
+            hipLaunchKernelGGL((k_stem_mfma<2, 256, false, true>), dim3((tiles + 4 * sm.tiles_per_wave - 1) / (4 * sm.tiles_per_wave)), dim3(256), 0, s, sm);
+        } else {
+            hipLaunchKernelGGL(k_stem_generic, dim3((unsigned)(((long)M * (SC / 8) + 255) / 256)), dim3(256), 0, s, st);
+        }
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
-        trunk_convs = 0;
+        trunk_convs = 0; fused_blocks = 0;
+        const bool fuse = gomoku && fused && blocks > 1;
+        bf16_t* cur = X;                            // raw trunk activation after the last block
         for (int i = 0; i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i), nb = "block" + std::to_string(i + 1);
             const bool first = i == 0, last = i + 1 == blocks;
+            if (fuse && !first) {                   // whole block in one kernel: raw x in, raw x out (pre-activation on load)
+                ResBlockArgs r; memset(&r, 0, sizeof(r));
+                r.xin = cur; r.xout = cur == X ? Hh : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
+                r.s1 = g(b + ".bn1.scale"); r.t1 = g(b + ".bn1.shift"); r.s2 = g(b + ".conv1.scale"); r.t2 = g(b + ".conv1.shift");
+                r.b2 = g(b + ".conv2.bias"); r.M = M; r.H = H; r.W = W;
+                rb3_launch(s, r, rb3_pick_tm(M, W, n_cus), 8);
+                cur = r.xout; fused_blocks++;
+                if (last) hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("p.bn0.scale"), g("p.bn0.shift"), Aa, (long)M * F / 8, F);
+                continue;
+            }
             const bf16_t* ain = first ? A0 : Aa;
-            const float* sB = last ? (gomoku ? g("p.bn0.scale") : nullptr) : g(nb + ".bn1.scale");
-            const float* tB = last ? (gomoku ? g("p.bn0.shift") : nullptr) : g(nb + ".bn1.shift");
+            const float* sB = last ? (gomoku ? g("p.bn0.scale") : nullptr) : (fuse ? nullptr : g(nb + ".bn1.scale"));
+            const float* tB = last ? (gomoku ? g("p.bn0.shift") : nullptr) : (fuse ? nullptr : g(nb + ".bn1.shift"));
             bf16_t* o2 = sB ? Aa : nullptr;
             if (gomoku) {
                 if (first) {
@@ -677,11 +817,16 @@ struct GenericEvaluator : Evaluator {
         }
         if (timing) hipEventRecord(e1, s);
         if (gomoku) {
-            hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, X, g("v.bn0.scale"), g("v.bn0.shift"), Va, (long)M * F / 8, F);
+            hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("v.bn0.scale"), g("v.bn0.shift"), Va, (long)M * F / 8, F);
             conv_mfma32(s, Aa, b16["p.c1.w"], g("p.c1.scale"), g("p.c1.shift"), PH, M);
             conv_mfma32(s, Va, b16["v.c1.w"], g("v.c1.scale"), g("v.c1.shift"), VH, M);
-            conv_direct(s, PH, g("p.c2.w"), 32, 8, 3, nullptr, g("p.c2.bias"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, pfeat, g("p.bn2.scale"), g("p.bn2.shift"), NACT_RELU, M);
-            conv_direct(s, VH, g("v.c2.w"), 32, 4, 1, nullptr, g("v.c2.bias"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, vfeat, g("v.bn2.scale"), g("v.bn2.shift"), NACT_RELU, M);
+            {
+                ConvSmallArgs c; c.in = PH; c.w = g("p.c2.w"); c.bias = g("p.c2.bias"); c.flat = pfeat; c.fs = g("p.bn2.scale"); c.ft = g("p.bn2.shift");
+                c.act = NACT_RELU; c.M = M; c.H = H; c.W = W;
+                hipLaunchKernelGGL((k_conv_small<8, 3>), dim3((M + 255) / 256), dim3(256), 0, s, c);
+                c.in = VH; c.w = g("v.c2.w"); c.bias = g("v.c2.bias"); c.flat = vfeat; c.fs = g("v.bn2.scale"); c.ft = g("v.bn2.shift");
+                hipLaunchKernelGGL((k_conv_small<4, 1>), dim3((M + 255) / 256), dim3(256), 0, s, c);
+            }
             dense(s, pfeat, "p.d1.w", g("p.d1.scale"), g("p.d1.shift"), pd1, n, HW * 8, 512, NACT_RELU);
             dense(s, pd1, "p.d2.w", nullptr, g("p.d2.bias"), plog, n, 512, A, NACT_NONE);
             dense(s, vfeat, "v.d1.w", g("v.d1.scale"), g("v.d1.shift"), vd1, n, HW * 4, 256, NACT_RELU);
@@ -703,7 +848,17 @@ struct GenericEvaluator : Evaluator {
     void timing_get(double* ms, int64_t* launches) override {
         double t = 0;
         for (size_t i = 0; i + 1 < tev.size(); i += 2) { float a = 0; hipEventElapsedTime(&a, tev[i], tev[i + 1]); t += a; }
-        *ms = t; *launches = (int64_t)(tev.size() / 2) * (trunk_convs > 0 ? trunk_convs : 1);
+        // launches of the dominant kernel inside the bracket: fused blocks (k_resblock3) or 128 -> 128 convs; block 0 of the
+        // Gomoku net (256 -> 128 + projection) rides in the same bracket and is counted as one more launch-equivalent
+        *ms = t; *launches = (int64_t)(tev.size() / 2) * (fused_blocks > 0 ? fused_blocks + 1 : (trunk_convs > 0 ? trunk_convs : 1));
+    }
+    const char* dominant_kernel(int n, double* flops) override {
+        const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
+        if (!gomoku) { *flops = 0; return ""; }
+        const bool fz = fused && blocks > 1;
+        *flops = fz ? 2 * conv : conv;
+        return fz ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
+                  : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
 };
 
@@ -714,6 +869,8 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     GenericEvaluator* e = new GenericEvaluator();
     e->H = H; e->W = W; e->C = C; e->A = A; e->HW = H * W; e->blocks = cfg.net_blocks; e->F = gomoku ? 128 : 64; e->nmax = cfg.n_games;
     e->logits = cfg.policy_is_logits; e->gomoku = gomoku;
+    e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
+    { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
     e->Hh = e->dalloc<bf16_t>(M * F); e->Va = e->dalloc<bf16_t>(M * F); e->PH = e->dalloc<bf16_t>(M * 32); e->VH = e->dalloc<bf16_t>(M * 32);
@@ -753,6 +910,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)k_resblock2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
+    hipFuncSetAttribute((const void*)(k_resblock4<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
