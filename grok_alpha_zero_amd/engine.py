@@ -45,7 +45,7 @@ _LIBS = {}
 
 
 def load_library(lib_path=None):
-    path = lib_path or DEFAULT_LIB
+    path = lib_path or os.environ.get("GAZ_ENGINE_LIB") or DEFAULT_LIB
     if path in _LIBS:
         return _LIBS[path]
     if not os.path.exists(path):
