@@ -35,7 +35,7 @@ GAZ_DEV uint32_t hash_row(const int8_t* s, int n, uint32_t seed) {
     return h;
 }
 
-template <int UNUSED> GAZ_KERNEL k_hash_eval(const int8_t* in, float* policy, float* value, int n, int row_bytes, int A, uint32_t salt) {
+template <int UNUSED> GAZ_KERNEL_WIDE k_hash_eval(const int8_t* in, float* policy, float* value, int n, int row_bytes, int A, uint32_t salt) {
 #ifdef GAZ_HOST_EMU
     const int first = block_id(), step = 1 << 30;
 #else

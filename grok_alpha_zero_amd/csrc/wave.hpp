@@ -18,6 +18,7 @@
 #define GAZ_DEV inline
 #define GAZ_HD inline
 #define GAZ_KERNEL inline void
+#define GAZ_KERNEL_WIDE inline void
 #define GAZ_SHARED static thread_local
 struct char4 { signed char x, y, z, w; };
 struct uint4 { unsigned int x, y, z, w; };
@@ -47,6 +48,7 @@ template <class T> inline T atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v;
 #define GAZ_TREE_WPE 3                             // measured (tools/tree_sweep.sh): 0.074 / 0.080 / 0.083 ms per PUCT wave at 3 / 2 / 4
 #endif
 #define GAZ_KERNEL __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAZ_TREE_WPE, GAZ_TREE_WPE))) void
+#define GAZ_KERNEL_WIDE __global__ void               // kernels launched with more than one wavefront per workgroup
 #define GAZ_SHARED __shared__
 namespace gaz {
 constexpr int WAVE = 64;
