@@ -26,8 +26,9 @@ template <class G> GAZ_KERNEL k_wave(DevParams<G> E, int g0, int g1) {
 
 template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) {
     GAZ_SHARED Scratch<G> S;
+    GAZ_SHARED GumbelLocal<G> L;
     const int g = g0 + block_id();
-    if (g < g1) g_game_step<G>(E, g, S);
+    if (g < g1) g_game_step<G>(E, g, S, L);
 }
 
 template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {

@@ -55,6 +55,20 @@ template <class G> GAZ_DEV int terminal_probe_unsorted(const int8_t* board, cons
     return nt;
 }
 
+// One coalesced read of a node record (header + N / W / logits / child / action blocks, and RAW[]) into LDS: a level of the
+// descent then costs ONE dependent HBM round trip instead of one per block touched (three cache lines, read several times).
+template <class G> GAZ_DEV NodeRef<G> g_stage_node(const DevParams<G>& E, int g, int node, Scratch<G>& S) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(node_at(E, g, 0, node).p);
+    constexpr int NW = (NodeLayout<G>::OFF_BOARD + 3) / 4, RW0 = NodeLayout<G>::SIZE / 4;
+    wave_sync();
+    for (int i = lane_id(); i < NW + G::APAD; i += WAVE) {
+        const uint32_t v = src[i < NW ? i : RW0 + (i - NW)];
+        if (i < NW) S.node[i] = v; else reinterpret_cast<uint32_t*>(S.raw)[i - NW] = v;
+    }
+    wave_sync();
+    return NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)};
+}
+
 // softmax in float64 over S.gam[0..n): x <- exp(x - max) / np.sum(...)   (MCTS_Gumbel.py:82-88)
 template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
     double mx = S.gam[0];
@@ -70,9 +84,10 @@ template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
 }
 
 // compute_pi(use_softmax=True) for node nd (MCTS_Gumbel.py:126-141 with :113-124, :99-103, :106-110).  Result f32 in S.pri.
-template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, int n, Scratch<G>& S, uint32_t& N_b_out,
+// nd may be the LDS copy of the record (g_stage_node); RAW is passed separately because it is not contiguous with the header.
+template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S, uint32_t& N_b_out,
                                            uint64_t& sumv_out) {
-    const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P(); const float* RAW = node_raw<G>(nd);
+    const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P();
     uint32_t nb = 0; uint64_t sumv = 0;
     for (int i = 0; i < n; ++i) { uint32_t v = N[i]; if (v > nb) nb = v; sumv += v; }              // uniform
     for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)L[i];
@@ -113,9 +128,9 @@ template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<
 }
 
 // deterministic_selection: argmax(pi - visits / (1 + sum(visits))) in float64, first maximum (MCTS_Gumbel.py:243)
-template <class G> GAZ_DEV int g_det_select(const DevParams<G>& E, const NodeRef<G>& nd, int n, Scratch<G>& S) {
+template <class G> GAZ_DEV int g_det_select(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S) {
     uint32_t nb; uint64_t sumv;
-    compute_pi<G>(E, nd, n, S, nb, sumv);
+    compute_pi<G>(E, nd, RAW, n, S, nb, sumv);
     double best = 0.0; int bi = 0x7fffffff;
     for (int i = lane_id(); i < n; i += WAVE) {
         double sc = (double)S.pri[i] - (double)nd.N()[i] / (double)(1 + sumv);
@@ -279,10 +294,10 @@ template <class G> GAZ_DEV void g_expand_post(const DevParams<G>& E, int g, Game
 // end of MCTS_Gumbel.run (MCTS_Gumbel.py:653-679) + Self_Play bookkeeping
 template <class G> GAZ_DEV void g_move_end(const DevParams<G>& E, int g, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts, Scratch<G>& S) {
     using RL = RecLayout<G>;
-    NodeRef<G> r = node_at(E, g, 0, ts.root);
+    NodeRef<G> r = g_stage_node<G>(E, g, ts.root, S);                           // LDS copy of the root record
     const int n = uni((int)r.hdr()->n_actions);
     uint32_t nb; uint64_t sumv;
-    compute_pi<G>(E, r, n, S, nb, sumv);                                        // pi in S.pri
+    compute_pi<G>(E, r, S.raw, n, S, nb, sumv);                                 // pi in S.pri
     uint8_t* rec = rec_of(E, g);
     const int ply = gs.n_hist;
     float* pol = reinterpret_cast<float*>(rec + RL::OFF_POL) + (size_t)ply * G::A;
@@ -307,11 +322,8 @@ template <class G> GAZ_DEV void g_move_end(const DevParams<G>& E, int g, GameSta
     wave_sync();
 }
 
-template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S) {
+template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts) {
     using RL = RecLayout<G>;
-    GameState<G>& gs = E.games[g];
-    GumbelState<G>& gu = reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
-    TreeState& ts = E.trees[(size_t)g * 2];
 
     if (uni(gs.pend_kind) == PEND_ROOT) {
         g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S);
@@ -397,10 +409,10 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
             tree_only++;
             // one simulation below root child `id`
             int node = ts.root, depth = 0, slot = id;
-            bool done = false, pending = false;
+            bool done = false, pending = false, staged = false;
             for (;;) {
-                NodeRef<G> nd = node_at(E, g, 0, node);
-                const int c = uni(nd.child()[slot]);
+                // below the root the record of `node` is already in LDS (staged for its deterministic_selection)
+                const int c = staged ? uni(NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)}.child()[slot]) : uni(node_at(E, g, 0, node).child()[slot]);
                 if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return; }
                 if (c == CHILD_NONE) {                                         // expand (node, slot)
                     if (lane_id() == 0) gu.pend_counts = 1;
@@ -417,8 +429,8 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
                     break;
                 }
                 node = c;
-                NodeRef<G> cn = node_at(E, g, 0, node);
-                slot = g_det_select<G>(E, cn, uni((int)cn.hdr()->n_actions), S);
+                NodeRef<G> cn = g_stage_node<G>(E, g, node, S); staged = true;
+                slot = g_det_select<G>(E, cn, S.raw, uni((int)cn.hdr()->n_actions), S);
             }
             if (pending) return;
             if (uni(*E.error)) return;
@@ -469,6 +481,27 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
         }
     }
     set_error(E.error, ERR_LOOP_GUARD);
+}
+
+// The state machine reads and writes its per-game state (phase, counters, candidate list ...) dozens of times per launch, each
+// one a dependent global-memory access.  The launch works on an LDS copy instead: one coalesced load on entry, one store on exit.
+template <class G> struct GumbelLocal { GameState<G> gs; GumbelState<G> gu; TreeState ts; };
+
+template <class T> GAZ_DEV void copy_words(T* dst, const T* src) {
+    static_assert(sizeof(T) % 4 == 0, "word copy");
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst); const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (int i = lane_id(); i < (int)(sizeof(T) / 4); i += WAVE) d[i] = s[i];
+}
+
+template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S, GumbelLocal<G>& L) {
+    GameState<G>* gsG = &E.games[g];
+    GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
+    TreeState* tsG = &E.trees[(size_t)g * 2];
+    copy_words(&L.gs, gsG); copy_words(&L.gu, guG); copy_words(&L.ts, tsG);
+    wave_sync();
+    g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
+    wave_sync();
+    copy_words(gsG, &L.gs); copy_words(guG, &L.gu); copy_words(tsG, &L.ts);
 }
 
 }  // namespace gaz

@@ -74,6 +74,7 @@ template <class G> struct Scratch {   // per-wave LDS
     double gam[G::APAD];
     PathEnt path[PATH_CAP];
     uint32_t node[(NodeLayout<G>::OFF_BOARD + 3) / 4];   // header + child arrays of the node being scored (one HBM round trip per level)
+    float raw[G::APAD];        // Gumbel: the RAW[] block of that node (evaluator values of the expanded children)
 };
 
 template <class T> GAZ_DEV T uni(T v) {
