@@ -113,7 +113,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
     for (int tm = 0; tm < TM; ++tm) {
         lrow[tm] = (wm * TM + tm) * 32 + l31;
         const long gr = m0 + lrow[tm];
-        const int cell = (int)(gr % HW), y = cell / a.W, x = cell % a.W;
+        const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
         unsigned m = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -248,7 +248,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
                     const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     const long gr = m0 + row;
                     if (gr >= a.M) continue;
-                    const long b = gr / HW; const int cell = (int)(gr % HW), f = cell * 8 + (col & 7);
+                    const unsigned gr32 = (unsigned)gr;                       // M < 2^31 (host-checked): 32-bit division
+                    const unsigned b = gr32 / (unsigned)HW; const int cell = (int)(gr32 - b * (unsigned)HW), f = cell * 8 + (col & 7);
                     const float v = acc[tm][tn][r] + tA;
                     if (col < 8) a.p_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.p_fs[f] + a.p_ft[f], 0.0f);
                     else a.v_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.v_fs[f] + a.v_ft[f], 0.0f);
