@@ -174,3 +174,37 @@ def test_replay_file_is_real_hdf5_with_the_reference_schema(tmp_path):
         out = subprocess.run([h5dump, "-H", store.path], capture_output=True, text=True).stdout
         assert 'DATASET "boards_0"' in out and "H5T_STD_I8LE" in out and "H5T_IEEE_F32LE" in out and "H5T_STD_U32LE" in out
         assert "( 11, 6, 7, 4 ) / ( H5S_UNLIMITED, 6, 7, 4 )" in out
+
+
+def test_orchestrator_run_loop_and_resume(tmp_path):
+    """Run() (<Game>/main.py:232-352, self-play half): generation folders, dataset files, resume from the highest generation and
+    from game_stats[2], train_fn hook.  TicTacToe on the one-lane emulation build; generations > 0 keep the synthetic evaluator
+    because weights_fn returns None."""
+    from grok_alpha_zero_amd.orchestrator import Run, current_generation, make_dataset_file, make_generation_folder
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    emu = os.path.join(emu_dir, "libgaz_emu.so")
+    root = str(tmp_path / "Grok_Zero_Train")
+    train = dict(games_per_generation=4, MCTS_iteration_limit=12, max_actions=9, num_explore_actions_first=2,
+                 num_explore_actions_second=1, c_puct_init=1.25, dirichlet_alpha=1.0, use_gumbel=False, total_generations=3)
+    # a generation interrupted after 2 of 4 games
+    make_generation_folder(root, 0); make_dataset_file(os.path.join(root, "0"))
+    short = dict(train, games_per_generation=2)
+    assert run_self_play(GAMES["TicTacToe"], ({}, short), os.path.join(root, "0"), n_games=2, seed=3, lib_path=emu) == 2
+    trained = []
+    log = []
+    stats = Run(GAMES["TicTacToe"], ({}, train), train_fn=lambda g, src, dst: trained.append((g, os.path.isdir(dst))),
+                weights_fn=lambda folder: None, root=root, n_games=2, seed=5, lib_path=emu, out=log.append)
+    assert [s["generation"] for s in stats] == [0, 1, 2]
+    assert stats[0]["played_now"] == 2 and stats[1]["played_now"] == 4            # generation 0 resumed from game_stats[2] = 2
+    assert trained == [(0, True), (1, True), (2, True)]
+    for g in range(3):
+        gs = ReplayStore(os.path.join(root, str(g))).game_stats()
+        assert gs[2] == 4 and gs[3] + gs[4] + gs[5] == 4
+    assert current_generation(root) == 3 and not ReplayStore(os.path.join(root, "3")).exists()   # folder made by the last train_fn call
+    assert any("Generation: 2 / 2" in l for l in log) and log[-1] == "-----------Training Done!-----------"
+    # starting again resumes at the highest generation folder and has nothing left to play in it once its file exists
+    make_dataset_file(os.path.join(root, "3"))
+    again = Run(GAMES["TicTacToe"], ({}, dict(train, total_generations=4)), root=root, n_games=2, seed=9, lib_path=emu, out=lambda *_: None)
+    assert [s["generation"] for s in again] == [3] and again[0]["played_now"] == 4
