@@ -57,7 +57,9 @@ def _lib():
         ("H5Dclose", C.c_int, [hid_t]), ("H5Dget_space", hid_t, [hid_t]), ("H5Dget_type", hid_t, [hid_t]),
         ("H5Dwrite", C.c_int, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]), ("H5Dread", C.c_int, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
         ("H5Tget_class", C.c_int, [hid_t]), ("H5Tget_size", C.c_size_t, [hid_t]), ("H5Tget_sign", C.c_int, [hid_t]), ("H5Tclose", C.c_int, [hid_t]),
-        ("H5Gget_info", C.c_int, [hid_t, C.POINTER(_GInfo)]),
+        ("H5Gget_info", C.c_int, [hid_t, C.POINTER(_GInfo)]), ("H5Gopen2", hid_t, [hid_t, C.c_char_p, hid_t]), ("H5Gclose", C.c_int, [hid_t]),
+        ("H5Pset_create_intermediate_group", C.c_int, [hid_t, C.c_uint]), ("H5Eset_auto2", C.c_int, [hid_t, C.c_void_p, C.c_void_p]),
+        ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]),
         ("H5Lget_name_by_idx", C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, C.c_char_p, C.c_size_t, hid_t]),
     ]:
         fn = getattr(L, f); fn.restype = res; fn.argtypes = args
@@ -116,6 +118,37 @@ class H5File:
             out.append(buf.value.decode())
         return out
 
+    def walk(self, group=""):
+        """paths of every dataset below `group`, in link-name order (groups are told from datasets by trying to open them)"""
+        L = _lib()
+        L.H5Eset_auto2(0, None, None)                              # probing a dataset with H5Gopen2 is expected to fail quietly
+        out = []
+
+        def rec(gid, prefix):
+            info = _GInfo()
+            L.H5Gget_info(gid, C.byref(info))
+            for i in range(info.nlinks):
+                n = L.H5Lget_name_by_idx(gid, b".", 0, 0, i, None, 0, 0)
+                buf = C.create_string_buffer(n + 1)
+                L.H5Lget_name_by_idx(gid, b".", 0, 0, i, buf, n + 1, 0)
+                name = buf.value.decode()
+                sub = L.H5Gopen2(gid, name.encode(), 0)
+                if sub >= 0:
+                    rec(sub, prefix + name + "/")
+                    L.H5Gclose(sub)
+                else:
+                    out.append(prefix + name)
+
+        if group:
+            gid = L.H5Gopen2(self.fid, group.encode(), 0)
+            if gid < 0:
+                raise KeyError(group)
+            rec(gid, group.rstrip("/") + "/")
+            L.H5Gclose(gid)
+        else:
+            rec(self.fid, "")
+        return out
+
     def create_dataset(self, name, data, maxshape=None, dtype=None):
         L = _lib()
         arr = np.ascontiguousarray(data, dtype=dtype)
@@ -129,7 +162,10 @@ class H5File:
         if any(m is None for m in maxshape):                       # unlimited dimensions need a chunked layout
             chunk = (hsize_t * rank)(*[max(1, s) for s in arr.shape])
             L.H5Pset_chunk(dcpl, rank, chunk)
-        ds = L.H5Dcreate2(self.fid, name.encode(), _g(_FILE_TYPES[arr.dtype]), space, 0, dcpl, 0)
+        lcpl = L.H5Pcreate(_g("H5P_CLS_LINK_CREATE_ID_g"))
+        L.H5Pset_create_intermediate_group(lcpl, 1)                # "layers/conv2d/vars/0" creates the groups on the way
+        ds = L.H5Dcreate2(self.fid, name.encode(), _g(_FILE_TYPES[arr.dtype]), space, lcpl, dcpl, 0)
+        L.H5Pclose(lcpl)
         if ds < 0:
             raise OSError(f"cannot create dataset {name}")
         if arr.size:

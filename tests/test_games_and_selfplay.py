@@ -208,3 +208,33 @@ def test_orchestrator_run_loop_and_resume(tmp_path):
     make_dataset_file(os.path.join(root, "3"))
     again = Run(GAMES["TicTacToe"], ({}, dict(train, total_generations=4)), root=root, n_games=2, seed=9, lib_path=emu, out=lambda *_: None)
     assert [s["generation"] for s in again] == [3] and again[0]["played_now"] == 4
+
+
+def test_keras_weight_file_round_trip(tmp_path):
+    """keras_weights.py: layout rules of Keras 3 weight files (layers/<class>_<k>/vars/<i>, sub-layers of ResNet_Block by attribute
+    name).  Parity unpinned (no reference weight file, no TensorFlow): the importer is checked against a file written with the
+    same rules, plus group naming and error reporting."""
+    from grok_alpha_zero_amd import h5io
+    if not h5io.available():
+        pytest.skip("libhdf5 not available")
+    import torch
+    from grok_alpha_zero_amd.keras_weights import load_keras_weights, save_keras_style
+    from grok_alpha_zero_amd.net import Connect4Net
+    src = Connect4Net(3, seed=5).randomize_bn()
+    path = str(tmp_path / "model.weights.h5")
+    save_keras_style(src, path)
+    with h5io.H5File(path, "r") as f:
+        names = f.walk("layers")
+    assert "layers/conv2d/vars/0" in names and "layers/res_net__block_2/conv2/vars/1" in names
+    assert "layers/batch_normalization_4/vars/3" in names and "layers/dense_5/vars/0" in names and "layers/conv2d_2/vars/1" in names
+    dst = load_keras_weights(path, Connect4Net(3, seed=99))
+    a, b = src.export_engine_weights(), dst.export_engine_weights()
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    x = torch.randint(-1, 2, (4, 6, 7, 4)).float()
+    with torch.no_grad():
+        pa, va = src.eval()(x); pb, vb = dst.eval()(x)
+    assert torch.equal(pa, pb) and torch.equal(va, vb)
+    with pytest.raises(KeyError):
+        load_keras_weights(path, Connect4Net(4, seed=1))                     # a fourth block the file does not have
