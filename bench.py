@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--waves-per-step", type=int, default=400)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "hash"])
     ap.add_argument("--max-tree-sims", type=int, default=0, help="evaluation-free simulations per game per wave (0 = library default)")
+    ap.add_argument("--cache-leg", type=int, default=22, help="log2 entries of the evaluation cache used by the extra with_eval_cache leg (0 = skip the leg)")
+    ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the on-device evaluation cache (SURVEY 8f rank 3); 0 = off (the headline number is measured with it off: every request goes through the evaluator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -96,7 +98,7 @@ def main():
     eng = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
                          evaluator=EVAL_RESNET if args.evaluator == "resnet" else EVAL_HASH, net_blocks=args.blocks,
                          hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
-                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims)
+                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims, eval_cache_log2=args.eval_cache)
     if args.evaluator == "resnet":
         eng.load_weights(net.export_engine_weights())
 
@@ -130,9 +132,9 @@ def main():
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
     delta = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]),
-                      s1["evals"] - s0["evals"], s1["sims"] - s0["sims"]], np.int64)
+                      s1["evals"] - s0["evals"], s1["sims"] - s0["sims"], s1["cache_hits"] - s0["cache_hits"]], np.int64)
     total = reduce_stats(delta, world)                      # the one collective of the path: counters only
-    positions, games, evals, sims = (int(x) for x in total)
+    positions, games, evals, sims, hits = (int(x) for x in total)
 
     if rank == 0:
         HWc = net.H * net.W
@@ -161,14 +163,46 @@ def main():
                                parallelism=f"games sharded x{world}, counters all-reduced"),
                    detail=dict(positions=positions, games_finished=games, evaluator_calls=evals, simulations=sims,
                                evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=sims / dt,
-                               eval_tflops=evals * fl["total"] / dt / 1e12,
+                               eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
+                               eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
                                ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
                                ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1)),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1 and args.config == "connect4":
             out["cpu_baseline"] = cpu_baseline(args, net)
-        print(json.dumps(out), flush=True)
     eng.close()
+    # ---- extra leg (not the headline): the same workload with the on-device evaluation cache (the reference's
+    # Connect4 config runs its Session_Cache too, max_cache_depth = 2).  Search results are bit-identical; requests that repeat a
+    # state already evaluated are answered from HBM inside the tree kernel and cost no wave.
+    if args.cache_leg and args.eval_cache == 0 and args.evaluator == "resnet":
+        eng2 = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
+                              evaluator=EVAL_RESNET, net_blocks=args.blocks, hash_salt=7, ring_capacity=0,
+                              search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm, c_visit=50.0, c_scale=1.0,
+                              policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims, eval_cache_log2=args.cache_leg)
+        eng2.load_weights(net.export_engine_weights())
+        for _ in range(args.warmup):
+            eng2.run_waves(args.waves_per_step)
+        eng2.synchronize(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        c0 = eng2.stats(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng2.run_waves(args.waves_per_step)
+        eng2.synchronize(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt2 = time.perf_counter() - t0
+        c1 = eng2.stats()
+        if world > 1:
+            tt = torch.tensor([dt2], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt2 = float(tt.item())
+        d2 = reduce_stats(np.array([int(c1["plies"] - c0["plies"]), c1["evals"] - c0["evals"], c1["cache_hits"] - c0["cache_hits"]], np.int64), world)
+        eng2.close()
+        if rank == 0:
+            out["with_eval_cache"] = dict(value=int(d2[0]) / dt2, unit="positions/s", entries_log2=args.cache_leg,
+                                          hit_fraction=int(d2[2]) / max(int(d2[1]), 1), ms_per_step=dt2 / args.steps * 1e3,
+                                          note="same search results bit for bit; NOT the headline value")
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

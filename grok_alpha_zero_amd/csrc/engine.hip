@@ -31,6 +31,13 @@ template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) {
     if (g < g1) g_game_step<G>(E, g, S, L);
 }
 
+// evaluation cache: store (state row, outputs) of every request the evaluator just answered; runs between the evaluator
+// pass and the next tree launch, so the tree kernels only ever read the table
+template <class G> GAZ_KERNEL k_cache_insert(DevParams<G> E, int g0, int g1) {
+    const int g = g0 + block_id();
+    if (g < g1) cache_insert<G>(E, g);
+}
+
 template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
@@ -116,6 +123,7 @@ template <class G> GAZ_KERNEL k_count(DevParams<G> E, int32_t* out) {   // out[0
     atomic_add(reinterpret_cast<unsigned long long*>(out + 2), (unsigned long long)gs.n_evals);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 4), (unsigned long long)gs.n_sims);
     atomic_add(reinterpret_cast<unsigned long long*>(out + 6), (unsigned long long)gs.n_plies);
+    atomic_add(reinterpret_cast<unsigned long long*>(out + 8), (unsigned long long)gs.n_hits);
 }
 
 // ------------------------------------------------------------------------------------------ engine
@@ -236,11 +244,18 @@ template <class G> struct EngineT : gaz_engine {
         if (dalloc(&E.nn_in, (size_t)n * G::HW * G::C + 64)) return 1;
         if (dalloc(&E.nn_policy, (size_t)n * G::A + 64)) return 1;
         if (dalloc(&E.nn_value, (size_t)n + 64)) return 1;
+        if (cfg.eval_cache_log2 < 0 || cfg.eval_cache_log2 > 28) return fail("eval_cache_log2 out of range (0 = off, at most 28)");
+        if (cfg.eval_cache_log2 > 0) {
+            const size_t slots = (size_t)1 << cfg.eval_cache_log2;
+            E.cache_stride = CacheLayout<G>::SIZE; E.cache_mask = (uint32_t)(slots - 1); E.cache_epoch = 1;
+            if (dalloc(&E.cache, slots * (size_t)E.cache_stride)) return 1;      // zeroed: tag 0 never matches (tags are odd)
+            if (dalloc(&E.cache_lock, slots)) return 1;
+        }
         if (dalloc(&E.stats, 8)) return 1;
         if (dalloc(&E.error, 4)) return 1;
         if (dalloc(&dN, (size_t)n * G::A) || dalloc(&dW, (size_t)n * G::A) || dalloc(&dP, (size_t)n * G::A) ||
             dalloc(&dPol, (size_t)n * G::A) || dalloc(&dRV, n) || dalloc(&dQ, n) || dalloc(&dChosen, n) ||
-            dalloc(&dPhase, n) || dalloc(&dPending, n) || dalloc(&dCount, 8) || dalloc(&dMoves, (size_t)n + G::MAXT) || dalloc(&dSlots, n)) return 1;
+            dalloc(&dPhase, n) || dalloc(&dPending, n) || dalloc(&dCount, 16) || dalloc(&dMoves, (size_t)n + G::MAXT) || dalloc(&dSlots, n)) return 1;
         std::string e2;
         eval = make_evaluator(cfg, G::H, G::W, G::C, G::A, &e2);
         if (!eval && cfg.evaluator != GAZ_EVAL_EXTERNAL) return fail("evaluator: " + e2);
@@ -295,6 +310,7 @@ template <class G> struct EngineT : gaz_engine {
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
         if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); }
+        if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
         n_waves_total++;
         return 0;
     }
@@ -310,7 +326,7 @@ template <class G> struct EngineT : gaz_engine {
         // opt-in (GAZ_PIPELINE=1): measured on Connect4 / 4096 games it LOSES 13 % (27.5k vs 31.5k positions/s) — the half-batch
         // evaluator passes pay the launch gaps and tails of ten small kernels twice, more than the hidden tree step is worth
         static const bool on = getenv("GAZ_PIPELINE") && atoi(getenv("GAZ_PIPELINE")) != 0;
-        if (!on || E.sync_moves || !eval || !eval->supports_row_base() || E.n_games < 1024) return false;
+        if (!on || E.sync_moves || !eval || !eval->supports_row_base() || E.n_games < 1024 || E.cache) return false;
         if (!pipeline_ready) {
             if (hipStreamCreate(&tstream) != hipSuccess) return false;
             for (int p = 0; p < 2; ++p) for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&pe[p][i], hipEventDisableTiming);
@@ -349,10 +365,10 @@ template <class G> struct EngineT : gaz_engine {
         return 0;                                   // `stream` ends with eval(B, n - 1): every tree step is ordered before it
     }
 
-    int counts(int32_t out[8]) {
-        HIP_OK(hipMemsetAsync(dCount, 0, 8 * sizeof(int32_t), stream));
+    int counts(int32_t out[10]) {
+        HIP_OK(hipMemsetAsync(dCount, 0, 10 * sizeof(int32_t), stream));
         GAZ_LAUNCH(k_count<G>, E.n_games, WAVE, stream, E, dCount);
-        HIP_OK(hipMemcpyAsync(out, dCount, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(out, dCount, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -365,7 +381,7 @@ template <class G> struct EngineT : gaz_engine {
         // PUCT: a move needs at most iter_limit + 2 evaluations; Gumbel can overshoot its budget (vpc >= 1 per survivor)
         const int max_waves = cfg.search == GAZ_SEARCH_GUMBEL ? 4 * (E.run_iterations + 3 * G::A) + 64
                                                              : (E.run_iterations < 3 * G::A ? 3 * G::A : E.run_iterations) + 8;
-        int32_t c[8];
+        int32_t c[10];
         for (int w = 0; w < max_waves + 16; w += 16) {
             for (int i = 0; i < 16; ++i) one_wave(true);
             if (counts(c)) return 1;
@@ -402,6 +418,7 @@ template <class G> struct EngineT : gaz_engine {
         // run the APPLY phase (do_action, win check, prune) up to the next evaluation request
         launch_wave();
         if (eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, false);
+        if (eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
         HIP_OK(hipGetLastError());
         return check_device_error();
     }
@@ -433,6 +450,7 @@ template <class G> struct EngineT : gaz_engine {
     int write_outputs(const float* policy, const float* value) override {
         HIP_OK(hipMemcpyAsync(E.nn_policy, policy, (size_t)E.n_games * G::A * 4, hipMemcpyHostToDevice, stream));
         HIP_OK(hipMemcpyAsync(E.nn_value, value, (size_t)E.n_games * 4, hipMemcpyHostToDevice, stream));
+        if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -483,13 +501,13 @@ template <class G> struct EngineT : gaz_engine {
 
     int get_stats(uint64_t out[16]) override {
         for (int i = 0; i < 16; ++i) out[i] = 0;
-        int32_t c[8];
+        int32_t c[10];
         if (counts(c)) return 1;
         unsigned long long s[8];
         HIP_OK(hipMemcpy(s, E.stats, sizeof(s), hipMemcpyDeviceToHost));
         for (int i = 0; i < 6; ++i) out[i] = s[i];
         memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
-        out[9] = (uint64_t)n_waves_total;
+        out[9] = (uint64_t)n_waves_total; memcpy(&out[10], c + 8, 8);
         return check_device_error();
     }
 

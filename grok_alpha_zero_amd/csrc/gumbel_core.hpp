@@ -352,6 +352,12 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             if (uni(gs.roots_todo) == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
             if (lane_id() == 0) gs.move_evals = 0;
             if (g_root_pre<G>(E, g, gs, ts, S)) {
+                if (E.cache && cache_probe<G>(E, g)) {                         // evaluation cache hit
+                    g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S);
+                    if (lane_id() == 0) { gs.roots_todo = 0; gs.n_evals += 1; gs.n_hits += 1; }
+                    wave_sync();
+                    continue;
+                }
                 if (lane_id() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = 0; }
                 wave_sync();
                 return;
@@ -399,7 +405,12 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 if (lane_id() == 0) { gu.stage = 1; gu.sims_left = gu.vpc; gu.pend_counts = 0; }
                 wave_sync();
                 if (uni(r.child()[id]) == CHILD_NONE) {
-                    if (g_expand_pre<G>(E, g, gs, ts, S, ts.root, id, 0)) return;
+                    if (g_expand_pre<G>(E, g, gs, ts, S, ts.root, id, 0)) {
+                        if (!(E.cache && cache_probe<G>(E, g))) return;
+                        g_expand_post<G>(E, g, gs, ts, S);                     // hit: not an iteration (pend_counts = 0)
+                        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
+                        wave_sync();
+                    }
                     if (uni(*E.error)) return;
                 }
                 continue;
@@ -432,7 +443,13 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 NodeRef<G> cn = g_stage_node<G>(E, g, node, S); staged = true;
                 slot = g_det_select<G>(E, cn, S.raw, uni((int)cn.hdr()->n_actions), S);
             }
-            if (pending) return;
+            if (pending) {
+                if (!(E.cache && cache_probe<G>(E, g))) return;
+                g_expand_post<G>(E, g, gs, ts, S);                             // hit: the simulation completes in this launch
+                if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
+                wave_sync();
+                done = true;
+            }
             if (uni(*E.error)) return;
             if (done && lane_id() == 0) { gu.sims_left -= 1; gu.cur_iter += 1; gs.n_sims += 1; }
             wave_sync();

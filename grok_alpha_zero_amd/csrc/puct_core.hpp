@@ -56,6 +56,8 @@ template <class G> struct DevParams {
     int8_t* nn_in;             // [n_games][HW*C]
     float* nn_policy;          // [n_games][A]
     float* nn_value;           // [n_games]
+    // evaluation cache (0 = off): direct-mapped, entry = [tag u32][pad u32][state row, 8-byte padded][policy f32 x A][value f32]
+    uint8_t* cache; uint32_t* cache_lock; uint32_t cache_mask, cache_epoch; int32_t cache_stride;
     unsigned long long* stats; // [8]: game_stats[0..5] (Self_Play.py:181-188), [6] waves, [7] spare
     int32_t* error;            // first error code, 0 = none
 };
@@ -406,6 +408,72 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// On-device evaluation cache (replaces Session_Cache.Cache_Wrapper, Session_Cache.py:4-26): encoded leaf state -> the evaluator's
+// policy / value for it.  Both trees of a game (and thousands of games) evaluate the same positions: in steady state a
+// third of the requests repeat (tools/dup_probe2.py).  A hit is consumed inside the same launch, so it costs no wave.
+// Tree kernels only READ the table; entries are written by k_cache_insert between the evaluator pass and the next tree
+// launch (kernel boundaries order the two), one writer per slot and wave (epoch lock).  The full state is stored and
+// compared, so a hit is exact; rows of an evaluator batch are independent, so the cached bits equal a fresh evaluation.
+template <class G> struct CacheLayout {
+    static constexpr int ROWB = G::HW * G::C, KEYB = (ROWB + 7) / 8 * 8;
+    static constexpr int OFF_KEY = 8, OFF_POL = OFF_KEY + KEYB, OFF_VAL = OFF_POL + 4 * G::A, SIZE = (OFF_VAL + 4 + 63) / 64 * 64;
+};
+
+GAZ_DEV uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+
+// order-independent 64-bit hash of the encoded row (each lane mixes the cells it owns, the wave adds)
+template <class G> GAZ_DEV uint64_t row_hash(const int8_t* row) {
+    uint64_t h = 0;
+    for (int c = lane_id(); c < G::HW; c += WAVE) {
+        uint32_t v = 0;
+        for (int k = 0; k < G::C; ++k) v |= (uint32_t)(uint8_t)row[c * G::C + k] << (8 * k);
+        h += mix64(((uint64_t)(c + 1) << 32) | v);
+    }
+    return wave_sum_u64(h);
+}
+
+// true: row g of nn_policy / nn_value now holds the cached outputs for row g of nn_in
+template <class G> GAZ_DEV bool cache_probe(const DevParams<G>& E, int g) {
+    using CL = CacheLayout<G>;
+    const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
+    const uint64_t h = mix64(row_hash<G>(row));
+    const uint8_t* ent = E.cache + (size_t)((uint32_t)h & E.cache_mask) * (size_t)E.cache_stride;
+    const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+    if (uni(*reinterpret_cast<const uint32_t*>(ent)) != tag) return false;
+    bool same = true;
+    for (int i = lane_id(); i < CL::ROWB; i += WAVE) same = same && (ent[CL::OFF_KEY + i] == (uint8_t)row[i]);
+    if (ballot(!same) != 0) return false;
+    const float* pol = reinterpret_cast<const float*>(ent + CL::OFF_POL);
+    for (int a = lane_id(); a < G::A; a += WAVE) E.nn_policy[(size_t)g * G::A + a] = pol[a];
+    if (lane_id() == 0) E.nn_value[g] = *reinterpret_cast<const float*>(ent + CL::OFF_VAL);
+    wave_sync();
+    return true;
+}
+
+// k_cache_insert body: game g's pending request was evaluated this wave -> store (row, outputs)
+template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
+    using CL = CacheLayout<G>;
+    if (uni(E.games[g].pend_kind) == PEND_NONE) return;
+    const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
+    const uint64_t h = mix64(row_hash<G>(row));
+    const uint32_t slot = (uint32_t)h & E.cache_mask;
+    uint32_t prev = 0;
+    if (lane_id() == 0) prev = atomic_exch(&E.cache_lock[slot], E.cache_epoch);     // one writer per slot and wave
+    if (uni(prev) == E.cache_epoch) return;
+    uint8_t* ent = E.cache + (size_t)slot * (size_t)E.cache_stride;
+    for (int i = lane_id(); i < CL::ROWB; i += WAVE) ent[CL::OFF_KEY + i] = (uint8_t)row[i];
+    float* pol = reinterpret_cast<float*>(ent + CL::OFF_POL);
+    for (int a = lane_id(); a < G::A; a += WAVE) pol[a] = E.nn_policy[(size_t)g * G::A + a];
+    if (lane_id() == 0) {
+        *reinterpret_cast<float*>(ent + CL::OFF_VAL) = E.nn_value[g];
+        *reinterpret_cast<uint32_t*>(ent) = (uint32_t)(h >> 32) | 1u;
+    }
+}
+
 // K4 first half (+K3, K5): expand the next child of `node`.  Returns true if an evaluation is pending
 // (row g written), false if the simulation completed here (terminal parent created and backed up).
 template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
@@ -671,6 +739,12 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
             if (todo == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
             const int t = (todo & 1) ? 0 : 1;
             if (root_pre<G>(E, g, gs, trees[t], t, S)) {
+                if (E.cache && cache_probe<G>(E, g)) {                 // evaluation cache hit: the root is complete in this launch
+                    root_post<G>(E, g, gs, trees[t], t, S);
+                    if (lane_id() == 0) { gs.roots_todo &= ~(1 << t); gs.n_evals += 1; gs.n_hits += 1; }
+                    wave_sync();
+                    continue;
+                }
                 if (lane_id() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = t; }
                 wave_sync();
                 return;
@@ -758,7 +832,12 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
                 if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
             } else {
-                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth)) return;
+                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth)) {
+                    if (!(E.cache && cache_probe<G>(E, g))) return;    // miss: the evaluator answers in the next launch
+                    expand_post<G>(E, g, gs, ts, t, S);                // hit: consume the cached outputs now
+                    if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
+                    wave_sync();
+                }
                 if (uni(*E.error)) return;
                 if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();

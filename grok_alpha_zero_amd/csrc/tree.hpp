@@ -88,6 +88,7 @@ template <class G> struct GameState {
     int32_t winner;
     uint32_t move_evals;       // evaluator calls during the current run()
     uint64_t n_evals, n_sims, n_plies;  // lifetime counters of this slot (n_plies = positions played)
+    uint64_t n_hits;           // evaluations answered by the on-device evaluation cache (included in n_evals)
 };
 
 // per-game record of the game in progress (and of finished games in the ring); see engine.hip for the

@@ -37,6 +37,7 @@ inline int ffsll0(uint64_t x) { return __builtin_ctzll(x); }   // index of lowes
 inline int flsll0(uint64_t x) { return 63 - __builtin_clzll(x); }
 template <class T> inline T atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomic_exch(T* p, T v) { T o = *p; *p = v; return o; }
 }  // namespace gaz
 #else
 #include <hip/hip_runtime.h>
@@ -68,6 +69,7 @@ GAZ_DEV int ffsll0(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 GAZ_DEV int flsll0(uint64_t x) { return 63 - __clzll((long long)x); }
 template <class T> GAZ_DEV T atomic_add(T* p, T v) { return atomicAdd(p, v); }
 template <class T> GAZ_DEV T atomic_max(T* p, T v) { return atomicMax(p, v); }
+template <class T> GAZ_DEV T atomic_exch(T* p, T v) { return atomicExch(p, v); }
 }  // namespace gaz
 #endif
 
@@ -96,5 +98,13 @@ GAZ_DEV void wave_argmax_u32(uint32_t& v, int& idx) {
         if (take) { v = ov; idx = oi; }
     }
 #endif
+}
+// wave sum of uint64 (wrap-around add: order-independent)
+GAZ_DEV uint64_t wave_sum_u64(uint64_t v) {
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+#endif
+    return v;
 }
 }  // namespace gaz

@@ -70,6 +70,9 @@ typedef struct {
     double opening_weights[8];
     int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 4);
                                        scheduling only — results do not depend on it */
+    int32_t eval_cache_log2;      /* on-device evaluation cache with 2^n entries, keyed by the encoded leaf state (replaces
+                                     Session_Cache.Cache_Wrapper, Session_Cache.py:4-26 / Self_Play.py:234-236); 0 = off.
+                                     A hit returns the bits the evaluator produced for the same input: results do not change */
 } gaz_engine_config;
 
 typedef struct {

@@ -155,3 +155,47 @@ def test_emu_opening_actions_match_reference(emu_lib, name):
     fx = np.load(os.path.join(GOLDEN, name + ".npz"))
     r = play_fixture(fx, emu_lib, opening_actions=list(zip(fx["opening_idx"].tolist(), fx["opening_w"].tolist())))
     assert_matches_fixture(r, fx)
+
+
+def _finished(eng, n_waves):
+    import hashlib
+    eng.run_waves(n_waves); eng.synchronize()
+    h = hashlib.sha256(); n = 0
+    for r in sorted(eng.drain_finished(), key=lambda r: (r["slot"], r["game_seq"])):
+        n += 1
+        for k in ("slot", "game_seq", "winner", "T"):
+            h.update(np.int64(r[k]).tobytes())
+        for k in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits"):
+            h.update(np.ascontiguousarray(r[k]).tobytes())
+    return n, h.hexdigest()
+
+
+@pytest.mark.parametrize("game,search,iters,max_actions", [("TicTacToe", 0, 30, 9), ("Connect4", 0, 24, 16), ("Connect4", 1, 16, 14)])
+def test_evaluation_cache_changes_nothing_but_the_wave_count(game, search, iters, max_actions):
+    """eval_cache_log2 > 0 (on-device evaluation cache): identical finished games — visit counts, W, priors,
+    policies, q, per-move evaluator-call counts — and a non-zero hit count; fewer launches are needed for the same games."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine
+    outs = []
+    for log2 in (0, 12):
+        eng = SelfPlayEngine(game, 24, iters, max_actions, 2, 1, 1.5, 0.8, seed=77, hash_salt=3, ring_capacity=4096, search=search,
+                             gumbel_m=4 if search else 0, eval_cache_log2=log2, lib_path=EMU)
+        outs.append(_finished(eng, 600) + (eng.stats()["cache_hits"], eng.stats()["evals"]))
+        eng.close()
+    (n0, h0, hits0, ev0), (n1, h1, hits1, ev1) = outs
+    assert hits0 == 0 and hits1 > 0
+    assert n0 > 24
+    # the cached run finishes at least as many games in the same number of launches; compare the common prefix of games
+    assert n1 >= n0
+    eng_a = SelfPlayEngine(game, 24, iters, max_actions, 2, 1, 1.5, 0.8, seed=77, hash_salt=3, ring_capacity=4096, search=search,
+                           gumbel_m=4 if search else 0, eval_cache_log2=0, lib_path=EMU)
+    eng_b = SelfPlayEngine(game, 24, iters, max_actions, 2, 1, 1.5, 0.8, seed=77, hash_salt=3, ring_capacity=4096, search=search,
+                           gumbel_m=4 if search else 0, eval_cache_log2=12, lib_path=EMU)
+    eng_a.run_waves(600); eng_b.run_waves(600)
+    ra = {(r["slot"], r["game_seq"]): r for r in eng_a.drain_finished()}
+    rb = {(r["slot"], r["game_seq"]): r for r in eng_b.drain_finished()}
+    common = sorted(set(ra) & set(rb))
+    assert len(common) >= n0 // 2
+    for k in common:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(ra[k][f]), np.asarray(rb[k][f]), err_msg=f"{k} {f}")
+    eng_a.close(); eng_b.close()

@@ -202,3 +202,27 @@ def test_hip_opening_actions_match_reference(name):
     for k in ("actions", "root_N", "root_visits", "root_W", "policies"):
         np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
     eng.close()
+
+
+def test_hip_evaluation_cache_gives_identical_games():
+    """eval_cache_log2 (on-device evaluation cache): with the HIP ResNet evaluator the finished games are bit-identical with the
+    cache on and off (rows of a batch are independent, so cached outputs equal fresh ones), and a good share of requests hit."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=3).eval().export_engine_weights()
+    got = []
+    for log2 in (0, 16):
+        eng = SelfPlayEngine("Connect4", 512, 32, 16, 4, 3, 2.5, 0.5, seed=21, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192,
+                             eval_cache_log2=log2)
+        eng.load_weights(w)
+        eng.run_waves(900); eng.synchronize()
+        st = eng.stats()
+        got.append(({(r["slot"], r["game_seq"]): r for r in eng.drain_finished()}, st["cache_hits"], st["evals"]))
+        eng.close()
+    (ra, h0, e0), (rb, h1, e1) = got
+    assert h0 == 0 and h1 > 0.1 * e1
+    common = sorted(set(ra) & set(rb))
+    assert len(common) >= 512 and len(rb) >= len(ra)
+    for k in common:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(ra[k][f]), np.asarray(rb[k][f]), err_msg=f"{k} {f}")
