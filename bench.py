@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--waves-per-step", type=int, default=400)
     ap.add_argument("--evaluator", default="resnet", choices=["resnet", "hash"])
     ap.add_argument("--max-tree-sims", type=int, default=0, help="evaluation-free simulations per game per wave (0 = library default)")
-    ap.add_argument("--cache-leg", type=int, default=22, help="log2 entries of the evaluation cache used by the extra with_eval_cache leg (0 = skip the leg)")
+    ap.add_argument("--cache-leg", type=int, default=-1, help="log2 entries of the evaluation cache used by the extra with_eval_cache leg (0 = skip the leg; default 24, Gomoku 0: 5 %% hits there)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the on-device evaluation cache (SURVEY 8f rank 3); 0 = off (the headline number is measured with it off: every request goes through the evaluator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -78,6 +78,8 @@ def main():
     args = parse()
     game, dG, dS, dB, max_actions, ef, es, cpuct, alpha, search, gm = CONFIGS[args.config]
     args.games = args.games or dG; args.sims = args.sims or dS; args.blocks = args.blocks or dB
+    if args.cache_leg < 0:
+        args.cache_leg = 0 if args.config == "gomoku" else 24
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))

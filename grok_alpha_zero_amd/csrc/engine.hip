@@ -225,7 +225,9 @@ template <class G> struct EngineT : gaz_engine {
             if (cfg.opening_actions[i] < 0 || cfg.opening_actions[i] >= G::A) return fail("opening action out of range");
             E.opening_actions[i] = cfg.opening_actions[i]; E.opening_weights[i] = cfg.opening_weights[i];
         }
-        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : 4;   // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms
+        // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms; with the evaluation cache a hit is such a simulation too and 8 pays
+        // (small boards; a Gomoku simulation is ten times as long and 8 only stretches the launch)
+        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : ((cfg.eval_cache_log2 > 0 && G::A <= 64) ? 8 : 4);
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
@@ -280,6 +282,10 @@ template <class G> struct EngineT : gaz_engine {
         if (!eval) return fail("no evaluator to load weights into");
         std::string m;
         if (eval->load(t, n, stream, &m)) return fail("load_weights: " + m);
+        if (E.cache) {                              // cached outputs belong to the previous weights
+            HIP_OK(hipMemsetAsync(E.cache, 0, ((size_t)E.cache_mask + 1) * (size_t)E.cache_stride, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+        }
         return 0;
     }
 

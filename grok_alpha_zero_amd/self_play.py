@@ -134,7 +134,7 @@ def record_to_samples(game_class, rec):
 
 
 def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
-                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None):
+                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22):
     """Generate `games_per_generation - game_stats[2]` self-play games into `folder_path` (Self_Play.py:259-272).
     `configs` = (build_config, train_config[, optimizer_config]).  `weights` = dict from net.export_engine_weights()
     (generation > 0); generation 0 (folder name "0") plays with the synthetic evaluator like the reference's
@@ -166,7 +166,8 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                          create_new_root=train_config.get("create_new_root", False), slot_offset=slot_offset, device=device,
                          evaluator=EVAL_RESNET if use_net else EVAL_HASH, hash_salt=hash_salt,
                          net_blocks=build_config.get("num_resnet_layers", 0) if use_net else 0,
-                         net_filters=build_config.get("num_filters", 128), ring_capacity=max(4 * G, 64), lib_path=lib_path)
+                         net_filters=build_config.get("num_filters", 128), ring_capacity=max(4 * G, 64), lib_path=lib_path,
+                         eval_cache_log2=eval_cache_log2)    # on-device Session_Cache (Self_Play.py:234-236): same games, fewer waves
     if use_net:
         eng.load_weights(weights)
     written = 0
