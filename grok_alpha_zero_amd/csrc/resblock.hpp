@@ -25,8 +25,6 @@ struct ResBlockArgs {
     const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
     const float* b2;                              // conv2 bias
     int M, H, W;
-    unsigned* cu_slots;                           // [8 XCC][256]: arrival counters per CU (k_resblock3 stagger), or null
-    int stagger_wgs, stagger_ticks;               // workgroups of the first round; delay of every second arrival on a CU (100 MHz ticks)
     unsigned long long* stamps;                   // diagnostic: [workgroup][RB_STAMPS]: 32 wall-clock ticks (100 MHz) + 32 shader-clock counts of wave 0, or null
 };
 
@@ -227,194 +225,12 @@ __global__ __launch_bounds__(RB_THREADS, 2) void k_resblock(ResBlockArgs a) {
     RB_STAMP(23);
 }
 
-// ---- k_resblock2: the same block with the weights OUT of LDS.  Stamps of k_resblock (tools/rb_stamps.py) showed a tap at
-// 3460 cycles against 2048 of pure MFMA: ~900 go to issuing the weight LDS-DMA (all eight waves at once, right after the
-// barrier) and ~500 to the per-tap barrier itself.  Here each wave owns 128 rows x 32 output channels (TM = 4, TN = 1) and
-// loads ITS B fragments straight from global memory (L2-resident, fragment order = one coalesced 16-byte load per lane and
-// k-step) into registers, one whole tap ahead.  The activation image is read-only during a conv, so the tap loop has no
-// barrier at all: waves drift freely and the two waves of a SIMD fill each other's stalls.  L2 -> CU weight traffic doubles
-// (64 KB per tap and workgroup), LDS holds the image only (74 KB); the epilogue goes through a 128-row fp32 tile twice.
-__global__ __launch_bounds__(RB_THREADS, 2) void k_resblock2(ResBlockArgs a) {
-    constexpr int BN = 128, SLOTS = 16, TM = 4, KS = 8;
-    constexpr int AROWS = CONV_AROWS_256, ZROW = AROWS - 1, BSL = BN * SLOTS;
-    extern __shared__ uint4 lds[];
-    uint4* As = lds;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, lhi = lane >> 5;
-    const int h = a.W + 1, HW = a.H * a.W, bmo = RB_ROWS - 2 * h;
-    const long m0 = (long)blockIdx.x * bmo;
-    const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
-    const int col = wn * 32 + l31;
-    RB_STAMP(0);
-
-    // ---- 1. image of x: image row q <-> global row m0 - 2h + q
-    const int n_aslots = (RB_ROWS + 2 * h) * SLOTS;
-    for (int base = wave * 64; base < n_aslots; base += RB_THREADS) {
-        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
-        long gr = m0 - 2 * h + lr;
-        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
-        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
-    }
-    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
-
-    // weights of the first tap, parameters
-    uint4 bfr[2][KS];
-    const uint4* wl = reinterpret_cast<const uint4*>(a.w1) + lhi * BN + col;      // + (ks * 2) * BN per k-step, + BSL per tap
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bfr[0][ks] = wl[ks * 2 * BN];
-    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
-    float ps1[8], pt1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ps1[j] = a.s1[tch0 + j]; pt1[j] = a.t1[tch0 + j]; }
-    const float ps2 = a.s2[col], pt2 = a.t2[col], pb2 = a.b2[col];
-
-    // per-lane geometry: conv1 row j <-> global m0 - h + j ; conv2 row i <-> global m0 + i
-    int lrow[TM]; unsigned vmask[2][TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        lrow[tm] = (wm * TM + tm) * 32 + l31;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const long gr = m0 + lrow[tm] - (which == 0 ? h : 0);
-            unsigned m = 0;
-            if (gr >= 0 && gr < a.M) {
-                const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = t / 3 - 1, dx = t % 3 - 1;
-                    m |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
-                }
-            }
-            vmask[which][tm] = m;
-        }
-    }
-    __syncthreads();                                // x image landed
-    RB_STAMP(1);
-
-    // ---- 2. in-place pre-activation of the image: relu(x * s1 + t1)
-    for (int i = tid; i < n_aslots; i += RB_THREADS) {
-        uint4 v = As[i];
-        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
-            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
-            w[j] = pack_bf16(lo, hi);
-        }
-        As[i] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __syncthreads();
-    RB_STAMP(2);
-
-    f32x16 acc[TM];
-    constexpr int EPI_IT = RB_ROWS / (RB_THREADS / 16);
-    uint4 resv[EPI_IT];
-#pragma unroll
-    for (int sl = 0; sl < 18; ++sl) {
-        const int conv = sl / 9, tap = sl % 9;
-        if (tap == 0) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
-        }
-        if (sl + 1 < 18) {                          // B fragments of the next tap: in flight during this tap's MFMAs
-            const uint4* wn4 = reinterpret_cast<const uint4*>(sl + 1 < 9 ? a.w1 : a.w2) + (size_t)((sl + 1) % 9) * BSL + lhi * BN + col;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bfr[(sl + 1) & 1][ks] = wn4[ks * 2 * BN];
-        }
-        if (sl == 14) {                             // residual rows of this thread's epilogue slots (L2 round trip hidden)
-#pragma unroll
-            for (int it = 0; it < EPI_IT; ++it) {
-                long gr = m0 + tid / 16 + it * (RB_THREADS / 16);
-                gr = gr < a.M ? gr : (long)a.M - 1;
-                resv[it] = *reinterpret_cast<const uint4*>(a.xin + (size_t)gr * BN + (tid % 16) * 8);
-            }
-        }
-        const int off = (tap / 3 - 1) * a.W + (tap % 3 - 1);
-        int abase[TM], axor[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const bool ok = (vmask[conv][tm] >> tap) & 1u;
-            const int ar = ok ? lrow[tm] + h + off : ZROW;
-            abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
-        }
-        uint4 afr[2][TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
-            }
-            const bf16x8 bf = *reinterpret_cast<bf16x8*>(&bfr[sl & 1][ks]);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf, acc[tm], 0, 0, 0);
-        }
-        RB_STAMP(3 + sl);
-        if (sl == 8) {
-            __syncthreads();                        // every wave is done with the x image
-            // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
-            bf16_t* Hs = reinterpret_cast<bf16_t*>(As);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float v = fmaxf(acc[tm][r] * ps2 + pt2, 0.0f);
-                    Hs[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (bf16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
-                }
-            __syncthreads();
-            RB_STAMP(21);
-        }
-    }
-    __syncthreads();                                // every wave is done with the h image
-
-    // ---- 6. epilogue, 128 rows at a time through an fp32 tile over the image region: + bias + residual, rows [m0, m0 + bmo)
-    constexpr int CT = BN + 4;
-    float* Ct = reinterpret_cast<float*>(lds);
-    static_assert((size_t)128 * CT * 4 <= (size_t)AROWS * SLOTS * 16, "epilogue tile must fit in the image region");
-    const int chunk = tid % 16, r0 = tid / 16;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    Ct[row * CT + col] = acc[tm][r] + pb2;
-                }
-        }
-        __syncthreads();
-        if (pass == 0) RB_STAMP(22);
-#pragma unroll
-        for (int it4 = 0; it4 < EPI_IT / 2; ++it4) {
-            const int it = pass * (EPI_IT / 2) + it4, rl = r0 + it4 * (RB_THREADS / 16), row = pass * 128 + rl;
-            const long gr = m0 + row;
-            if (row < bmo && gr < a.M) {
-                const float4 c0 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8]);
-                const float4 c1 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8 + 4]);
-                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                const size_t o = (size_t)gr * BN + chunk * 8;
-                const unsigned rw[4] = {resv[it].x, resv[it].y, resv[it].z, resv[it].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(rw[j] << 16); v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u); }
-                *reinterpret_cast<uint4*>(a.xout + o) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-            }
-        }
-        if (pass == 0) __syncthreads();
-    }
-    RB_STAMP(23);
-}
-
-// ---- k_resblock3: k_resblock2's barrier-free taps in 256-thread workgroups, TWO per CU.  k_resblock2's stamps: taps at
-// ~84 % of the MFMA rate, but 37 % of a workgroup's life (image DMA wait, transform, h write, epilogue) leaves the matrix
-// cores idle because one 8-wave workgroup owns the CU.  Here a workgroup is 4 waves (one per SIMD), each 128 rows x 64
+// ---- k_resblock3: the same block with the weights OUT of LDS and barrier-free taps, in 256-thread workgroups, TWO per CU.
+// Stamps of k_resblock (tools/rb_stamps.py): a tap took 3460 cycles against 2048 of pure MFMA — ~900 went to issuing the
+// weight LDS-DMA (all eight waves at once, right after the barrier), ~500 to the per-tap barrier — and 37 % of a workgroup's
+// life (image DMA wait, transform, h write, epilogue) left the matrix cores idle because one 8-wave workgroup owned the CU.
+// Here each wave loads ITS B fragments straight from L2 into registers, the image is read-only during a conv (no barrier in
+// the tap loop), and a workgroup is 4 waves (one per SIMD), each 128 rows x 64
 // channels (TM = 4, TN = 2: 8 MFMAs per 4 LDS fragment reads); LDS is the 74-KB image only, so two workgroups share a CU
 // and one's serial phases hide behind the other's MFMAs.  B fragments: a four-k-step register ring fed from L2.
 // TM picks the tile height (ROWS = 64 * TM image rows computed, ROWS - 2(W+1) of them valid outputs): the host takes the TM
@@ -488,22 +304,6 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
             }
         }
         vmask[tm] = mm;
-    }
-    // Stagger: the two workgroups a CU receives in the first round start in lockstep, so their DMA waits, transforms, h writes
-    // and epilogues coincide and leave the matrix cores idle.  Every second arrival on a CU (HW_ID -> per-CU counter) holds
-    // back for stagger_ticks after its image has landed; later rounds inherit the offset.
-    if (a.cu_slots && (int)blockIdx.x < a.stagger_wgs) {
-        __shared__ unsigned s_order;
-        if (tid == 0) {
-            const unsigned cu = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);        // HW_ID[15:8]: CU, SH, SE
-            const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // XCC_ID[3:0]
-            s_order = atomicAdd(&a.cu_slots[(xcc & 7) * 256 + cu], 1u);
-        }
-        __syncthreads();
-        if (s_order & 1u) {
-            const unsigned long long t_end = wall_clock64() + (unsigned long long)a.stagger_ticks;
-            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
-        }
     }
     __syncthreads();                                // x image landed
     RB_STAMP(1);
@@ -629,211 +429,6 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
         if (pass == 0) RB_STAMP(22);
 #pragma unroll
         for (int q = 0; q < 2 * TM; ++q) {          // 2 * TM rows per thread and pass
-            const int rl = r0 + q * (RB3_THREADS / 16), row = pass * HR + rl;
-            const long gr = m0 + row;
-            if (row < bmo && gr < a.M) {
-                const float4 c0 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8]);
-                const float4 c1 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8 + 4]);
-                float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                const size_t o = (size_t)gr * BN + chunk * 8;
-                const uint4 rq = resv[pass * 2 * TM + q];
-                const unsigned rw[4] = {rq.x, rq.y, rq.z, rq.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(rw[j] << 16); v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u); }
-                *reinterpret_cast<uint4*>(a.xout + o) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-            }
-        }
-        if (pass == 0) __syncthreads();
-    }
-    RB_STAMP(23);
-}
-
-// ---- k_resblock4: k_resblock3 on the 16x16x32 MFMA shape.  Same tiles, same LDS image, same weight array and the same bytes
-// per MFMA-FLOP from LDS and L2; the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7), and
-// k_resblock3 is clock-bound.  Fragments: A lane l = row l & 15, k-octet l >> 4 of a 32-wide k-step; B lane l = channel l & 15,
-// same k-octet; C/D lane l = channel l & 15, rows 4 (l >> 4) + r.  Wave tile 32 TM rows x 64 channels = 2 TM x 4 MFMA tiles.
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-template <int TM, int RING>
-__global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock4(ResBlockArgs a) {
-    constexpr int BN = 128, SLOTS = 16, TI = 2 * TM, TJ = 4, KS = 4, ROWS = rb3_rows<TM>();
-    constexpr int AROWS = ROWS + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1, BSL = BN * SLOTS;
-    static_assert(KS % RING == 0, "ring slot must not depend on the tap");
-    extern __shared__ uint4 lds[];
-    uint4* As = lds;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, kq = lane >> 4;
-    const int h = a.W + 1, HW = a.H * a.W, bmo = ROWS - 2 * h;
-    const long m0 = (long)blockIdx.x * bmo;
-    const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
-    const int col0 = wn * 64 + l15;                 // + 16 * j
-    RB_STAMP(0);
-
-    // ---- 1. image of x: image row q <-> global row m0 - 2h + q
-    const int n_aslots = (ROWS + 2 * h) * SLOTS;
-    for (int base = wave * 64; base < n_aslots; base += RB3_THREADS) {
-        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
-        long gr = m0 - 2 * h + lr;
-        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
-        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
-    }
-    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
-
-    // weights: [slice 0..17][k-octet 0..15][cout][8 bf16]; fragment (slice, k-step s, j) = octet 4 s + kq, channel col0 + 16 j
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, 18 * BSL * 16, 0x00020000);
-    const int bvo = (kq * BN + col0) * 16;
-    auto ldb = [&](int slice, int ks, int j) -> uint4 {
-        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, ((slice * BSL) + ks * 4 * BN + j * 16) * 16, 0);
-        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
-    };
-    uint4 bfr[RING][TJ];
-#pragma unroll
-    for (int g = 0; g < RING; ++g)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) bfr[g][j] = ldb(0, g, j);
-    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
-    float ps1[8], pt1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ps1[j] = a.s1[tch0 + j]; pt1[j] = a.t1[tch0 + j]; }
-    float ps2[TJ], pt2[TJ], pb2[TJ];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) { ps2[j] = a.s2[col0 + j * 16]; pt2[j] = a.t2[col0 + j * 16]; pb2[j] = a.b2[col0 + j * 16]; }
-
-    int lrow[TI]; unsigned vmask[TI];               // bits 0-8: conv1 taps, 9-17: conv2 taps
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        lrow[i] = wm * (32 * TM) + i * 16 + l15;
-        unsigned mm = 0;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const long gr = m0 + lrow[i] - (which == 0 ? h : 0);
-            if (gr >= 0 && gr < a.M) {
-                const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = t / 3 - 1, dx = t % 3 - 1;
-                    mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << (which * 9 + t);
-                }
-            }
-        }
-        vmask[i] = mm;
-    }
-    __syncthreads();                                // x image landed
-    RB_STAMP(1);
-
-    // ---- 2. in-place pre-activation of the image: relu(x * s1 + t1)
-    for (int i = tid; i < n_aslots; i += RB3_THREADS) {
-        uint4 v = As[i];
-        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
-            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
-            w[j] = pack_bf16(lo, hi);
-        }
-        As[i] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __syncthreads();
-    RB_STAMP(2);
-
-    f32x4 acc[TI][TJ];
-#pragma unroll
-    for (int conv = 0; conv < 2; ++conv) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int sl = conv * 9 + tap;
-            const int nsl = sl + 1 < 18 ? sl + 1 : sl;
-            const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
-            int abase[TI], axor[TI];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const bool ok = (vmask[i] >> sl) & 1u;
-                const int ar = ok ? lrow[i] + h + off : ZROW;
-                abase[i] = ar * SLOTS; axor[i] = ar & 15;
-            }
-            uint4 afr[2][TI];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) afr[0][i] = As[abase[i] + (kq ^ axor[i])];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks + 1 < KS) {
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) afr[nxt][i] = As[abase[i] + (((ks + 1) * 4 + kq) ^ axor[i])];
-                }
-                bf16x8 bf[TJ];
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][j]);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][i]), bf[j], acc[i][j], 0, 0, 0);
-                if (ks + RING < KS) {
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) bfr[ks % RING][j] = ldb(sl, ks + RING, j);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) bfr[ks % RING][j] = ldb(nsl, ks + RING - KS, j);
-                }
-            }
-            RB_STAMP(3 + sl);
-        }
-        if (conv == 0) {
-            __syncthreads();                        // every wave is done with the x image
-            // ---- 4. h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
-            bf16_t* Hs = reinterpret_cast<bf16_t*>(As);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    const int col = col0 + j * 16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = wm * (32 * TM) + i * 16 + kq * 4 + r;
-                        const float v = fmaxf(acc[i][j][r] * ps2[j] + pt2[j], 0.0f);
-                        Hs[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (bf16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
-                    }
-                }
-            __syncthreads();
-            RB_STAMP(21);
-        }
-    }
-    uint4 resv[4 * TM];
-#pragma unroll
-    for (int q = 0; q < 4 * TM; ++q) {
-        long gr = m0 + (q / (2 * TM)) * (ROWS / 2) + tid / 16 + (q % (2 * TM)) * (RB3_THREADS / 16);
-        gr = gr < a.M ? gr : (long)a.M - 1;
-        resv[q] = *reinterpret_cast<const uint4*>(a.xin + (size_t)gr * BN + (tid % 16) * 8);
-    }
-    __syncthreads();                                // every wave is done with the h image
-
-    // ---- 6. epilogue, half the rows at a time through an fp32 tile over the image region: + bias + residual, rows [m0, m0 + bmo)
-    constexpr int CT = BN + 4, HR = ROWS / 2;
-    float* Ct = reinterpret_cast<float*>(lds);
-    static_assert((size_t)HR * CT * 4 <= (size_t)AROWS * SLOTS * 16, "epilogue tile must fit in the image region");
-    const int chunk = tid % 16, r0 = tid / 16;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Ct[(i * 16 + kq * 4 + r) * CT + col0 + j * 16] = acc[i][j][r] + pb2[j];
-        }
-        __syncthreads();
-        if (pass == 0) RB_STAMP(22);
-#pragma unroll
-        for (int q = 0; q < 2 * TM; ++q) {
             const int rl = r0 + q * (RB3_THREADS / 16), row = pass * HR + rl;
             const long gr = m0 + row;
             if (row < bmo && gr < a.M) {

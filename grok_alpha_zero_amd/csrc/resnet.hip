@@ -449,7 +449,6 @@ struct ResNetEvaluator : Evaluator {
     bf16_t *X = nullptr, *Aa = nullptr, *Hh = nullptr, *X2 = nullptr;
     bool fused = true;
     int stamp_calls = 0, n_cus = 256;
-    unsigned* cu_slots = nullptr;
     bf16_t* stem_frag = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
@@ -558,27 +557,19 @@ struct ResNetEvaluator : Evaluator {
             ResBlockArgs r; r.xin = cur; r.xout = cur == X ? X2 : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
             r.s1 = f32[b + ".bn1.scale"]; r.t1 = f32[b + ".bn1.shift"]; r.s2 = f32[b + ".conv1.scale"]; r.t2 = f32[b + ".conv1.shift"];
             r.b2 = f32[b + ".conv2.bias"]; r.M = M; r.H = H; r.W = W; r.stamps = nullptr;
-            static const int stagger_us10 = getenv("GAZ_RB_STAGGER") ? atoi(getenv("GAZ_RB_STAGGER")) : 0;    // tenths of a microsecond
-            r.cu_slots = stagger_us10 > 0 ? cu_slots : nullptr; r.stagger_wgs = 2 * n_cus; r.stagger_ticks = stagger_us10 * 10;
             static const int rbv = getenv("GAZ_RB") ? atoi(getenv("GAZ_RB")) : 3;
             static const int rb_tm = getenv("GAZ_RB_TM") ? atoi(getenv("GAZ_RB_TM")) : 0;
             static const int rb_ring = getenv("GAZ_RB_RING") ? atoi(getenv("GAZ_RB_RING")) : 8;
             // k_resblock3: tile height 64 * TM; take the TM with the least (rounds of 512 workgroups) x (tile cost ~ TM)
             int tm = rb_tm;
-            if (rbv >= 3 && tm == 0) tm = rb3_pick_tm(M, W, n_cus);
-            const int bmo = (rbv >= 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
+            if (rbv == 3 && tm == 0) tm = rb3_pick_tm(M, W, n_cus);
+            const int bmo = (rbv == 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
             const int nwg = (M + bmo - 1) / bmo;
             static const char* stamp_path = getenv("GAZ_RB_STAMPS");       // diagnostic: phase stamps of one launch -> file
             const bool stamp = stamp_path && i == 1 && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * RB_STAMPS * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * RB_STAMPS * 8, s); }
-            if (rbv == 4) {
-                if (tm == 2) hipLaunchKernelGGL((k_resblock4<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
-                else if (tm == 3 && rb_ring == 2) hipLaunchKernelGGL((k_resblock4<3, 2>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
-                else if (tm == 3) hipLaunchKernelGGL((k_resblock4<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
-                else hipLaunchKernelGGL((k_resblock4<4, 2>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
-            } else if (rbv == 3) rb3_launch(s, r, tm, rb_ring);
-            else if (rbv == 2) hipLaunchKernelGGL(k_resblock2, dim3(nwg), dim3(RB_THREADS), (size_t)CONV_AROWS_256 * 256, s, r);
+            if (rbv == 3) rb3_launch(s, r, tm, rb_ring);
             else hipLaunchKernelGGL(k_resblock, dim3(nwg), dim3(RB_THREADS), lds, s, r);
             if (stamp) {
                 std::vector<unsigned long long> hst((size_t)nwg * RB_STAMPS);
@@ -899,8 +890,6 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->logits = cfg.policy_is_logits;
     const size_t M = (size_t)cfg.n_games * e->HW;
     e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
-    e->cu_slots = e->dalloc<unsigned>(8 * 256);
-    if (e->cu_slots) hipMemset(e->cu_slots, 0, 8 * 256 * sizeof(unsigned));
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
@@ -908,9 +897,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     if (!e->X || !e->Aa || !e->Hh || !e->pfeat || !e->vfeat || !e->pd1 || !e->vd1) { *err = "hipMalloc failed"; delete e; return nullptr; }
     // dynamic LDS above 64 KB needs the attribute
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_resblock2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
-    hipFuncSetAttribute((const void*)(k_resblock4<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
