@@ -20,8 +20,9 @@ static std::string g_create_error;
 // one wavefront per game of [g0, g1)
 template <class G> GAZ_KERNEL k_wave(DevParams<G> E, int g0, int g1) {
     GAZ_SHARED Scratch<G> S;
+    GAZ_SHARED PuctLocal<G> L;
     const int g = g0 + block_id();
-    if (g < g1) game_step<G>(E, g, S);
+    if (g < g1) game_step<G>(E, g, S, L);
 }
 
 template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) {

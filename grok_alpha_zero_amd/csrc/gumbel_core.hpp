@@ -504,21 +504,15 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
 // one a dependent global-memory access.  The launch works on an LDS copy instead: one coalesced load on entry, one store on exit.
 template <class G> struct GumbelLocal { GameState<G> gs; GumbelState<G> gu; TreeState ts; };
 
-template <class T> GAZ_DEV void copy_words(T* dst, const T* src) {
-    static_assert(sizeof(T) % 4 == 0, "word copy");
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst); const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    for (int i = lane_id(); i < (int)(sizeof(T) / 4); i += WAVE) d[i] = s[i];
-}
-
 template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S, GumbelLocal<G>& L) {
     GameState<G>* gsG = &E.games[g];
     GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
     TreeState* tsG = &E.trees[(size_t)g * 2];
-    copy_words(&L.gs, gsG); copy_words(&L.gu, guG); copy_words(&L.ts, tsG);
+    copy_state_words(&L.gs, gsG); copy_state_words(&L.gu, guG); copy_state_words(&L.ts, tsG);
     wave_sync();
     g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
     wave_sync();
-    copy_words(gsG, &L.gs); copy_words(guG, &L.gu); copy_words(tsG, &L.ts);
+    copy_state_words(gsG, &L.gs); copy_state_words(guG, &L.gu); copy_state_words(tsG, &L.ts);
 }
 
 }  // namespace gaz

@@ -705,10 +705,8 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
 }
 
 // One launch of the wave kernel for game g: consume the pending evaluation, then run until the next one.
-template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S) {
+template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, TreeState* trees) {
     using RL = RecLayout<G>;
-    GameState<G>& gs = E.games[g];
-    TreeState* trees = E.trees + (size_t)g * 2;
 
     if (uni(gs.pend_kind) == PEND_ROOT) {
         const int t = uni(gs.pend_tree);
@@ -898,6 +896,28 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
         }
     }
     set_error(E.error, ERR_LOOP_GUARD);
+}
+
+// The state machine touches its per-game state (phase, counters, pending request, both tree heads) dozens of times per launch,
+// each one a dependent global-memory access.  Without re-root compaction (where node_at() reads TreeState::half from HBM) the
+// launch works on an LDS copy: one coalesced load on entry, one store on exit.
+template <class G> struct PuctLocal { GameState<G> gs; TreeState ts[2]; };
+
+template <class T> GAZ_DEV void copy_state_words(T* dst, const T* src) {
+    static_assert(sizeof(T) % 4 == 0, "word copy");
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst); const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (int i = lane_id(); i < (int)(sizeof(T) / 4); i += WAVE) d[i] = s[i];
+}
+
+template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {
+    GameState<G>* gsG = &E.games[g];
+    TreeState* tsG = E.trees + (size_t)g * 2;
+    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); return; }
+    copy_state_words(&L.gs, gsG); copy_state_words(&L.ts[0], &tsG[0]); copy_state_words(&L.ts[1], &tsG[1]);
+    wave_sync();
+    game_step_body<G>(E, g, S, L.gs, L.ts);
+    wave_sync();
+    copy_state_words(gsG, &L.gs); copy_state_words(&tsG[0], &L.ts[0]); copy_state_words(&tsG[1], &L.ts[1]);
 }
 
 }  // namespace gaz
