@@ -212,11 +212,11 @@ template <class G> GAZ_DEV bool g_root_pre(const DevParams<G>& E, int g, GameSta
 }
 
 // children of a freshly evaluated node: raw logits of the legal actions in legal order (normalize=False), all unexpanded
-template <class G> GAZ_DEV void g_write_children(const DevParams<G>& E, int g, const NodeRef<G>& nd, Scratch<G>& S) {
-    copy_board<G>(S.board, nd.board());
-    wave_sync();
+// `fresh`: S.board already is this node's board (same launch as g_expand_pre / g_root_pre: evaluation-cache hit)
+template <class G> GAZ_DEV void g_write_children(const DevParams<G>& E, int g, const NodeRef<G>& nd, Scratch<G>& S, const float* policy,
+                                                 bool fresh = false) {
+    if (!fresh) { copy_board<G>(S.board, nd.board()); wave_sync(); }
     const int n_legal = build_legal<G>(S.board, S.legal);
-    const float* policy = E.nn_policy + (size_t)g * G::A;
     for (int i = lane_id(); i < n_legal; i += WAVE) {
         nd.N()[i] = 0u; nd.W()[i] = 0.0f; node_raw<G>(nd)[i] = 0.0f; nd.P()[i] = policy[S.legal[i]];
         nd.child()[i] = CHILD_NONE; nd.act()[i] = S.legal[i];
@@ -278,15 +278,18 @@ template <class G> GAZ_DEV bool g_expand_pre(const DevParams<G>& E, int g, GameS
     return true;
 }
 
-template <class G> GAZ_DEV void g_expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S) {
+template <class G> GAZ_DEV void g_expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S,
+                                              const float* policy, const float* value_p, bool fresh = false) {
     const int node = gs.pend_parent, index = gs.pend_slot, idx = gs.pend_node, depth = gs.pend_depth;
     NodeRef<G> nd = node_at(E, g, 0, idx);
-    g_write_children<G>(E, g, nd, S);
+    g_write_children<G>(E, g, nd, S, policy, fresh);
     NodeRef<G> pn = node_at(E, g, 0, node);
-    const float value = E.nn_value[g];
+    const float value = *value_p;
     if (lane_id() == 0) { pn.child()[index] = idx; node_raw<G>(pn)[index] = value; }       // MCTS_Gumbel.py:516-517
-    const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
-    for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    if (!fresh) {
+        const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+        for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    }
     wave_sync();
     backup<G>(E, g, 0, ts, S.path, depth, -value, 1u);
 }
@@ -326,11 +329,11 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
     using RL = RecLayout<G>;
 
     if (uni(gs.pend_kind) == PEND_ROOT) {
-        g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S);
+        g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S, E.nn_policy + (size_t)g * G::A);
         if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo = 0; gs.n_evals += 1; }
         wave_sync();
     } else if (uni(gs.pend_kind) == PEND_EXPAND) {
-        g_expand_post<G>(E, g, gs, ts, S);
+        g_expand_post<G>(E, g, gs, ts, S, E.nn_policy + (size_t)g * G::A, E.nn_value + g);
         if (lane_id() == 0) {
             gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1;
             if (gu.pend_counts) { gu.sims_left -= 1; gu.cur_iter += 1; gs.n_sims += 1; }
@@ -352,8 +355,9 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             if (uni(gs.roots_todo) == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
             if (lane_id() == 0) gs.move_evals = 0;
             if (g_root_pre<G>(E, g, gs, ts, S)) {
-                if (E.cache && cache_probe<G>(E, g)) {                         // evaluation cache hit
-                    g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S);
+                const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                if (hit) {                                                     // evaluation cache hit
+                    g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL), true);
                     if (lane_id() == 0) { gs.roots_todo = 0; gs.n_evals += 1; gs.n_hits += 1; }
                     wave_sync();
                     continue;
@@ -406,8 +410,10 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 wave_sync();
                 if (uni(r.child()[id]) == CHILD_NONE) {
                     if (g_expand_pre<G>(E, g, gs, ts, S, ts.root, id, 0)) {
-                        if (!(E.cache && cache_probe<G>(E, g))) return;
-                        g_expand_post<G>(E, g, gs, ts, S);                     // hit: not an iteration (pend_counts = 0)
+                        const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                        if (!hit) return;
+                        g_expand_post<G>(E, g, gs, ts, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
+                                         reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: not an iteration (pend_counts = 0)
                         if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                         wave_sync();
                     }
@@ -444,8 +450,10 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 slot = g_det_select<G>(E, cn, S.raw, uni((int)cn.hdr()->n_actions), S);
             }
             if (pending) {
-                if (!(E.cache && cache_probe<G>(E, g))) return;
-                g_expand_post<G>(E, g, gs, ts, S);                             // hit: the simulation completes in this launch
+                const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                if (!hit) return;
+                g_expand_post<G>(E, g, gs, ts, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
+                                 reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: the simulation completes in this launch
                 if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                 wave_sync();
                 done = true;

@@ -334,12 +334,14 @@ template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState
 }
 
 // K12 second half: the evaluator's policy row -> root priors (the value is discarded, MCTS.py:346-365)
-template <class G> GAZ_DEV void root_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+// `policy`: row g of the evaluator output, or the policy block of an evaluation-cache entry
+template <class G> GAZ_DEV void root_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
+                                          const float* policy) {
     NodeRef<G> nd = node_at(E, g, t, ts.root);
     copy_board<G>(S.board, nd.board());
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
-    make_priors<G>(E, g, gs, ts, t, S, E.nn_policy + (size_t)g * G::A, n_legal);
+    make_priors<G>(E, g, gs, ts, t, S, policy, n_legal);
     write_children_from_scratch<G>(nd, S, n_legal);
     if (lane_id() == 0) { nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0; }
     wave_sync();
@@ -425,33 +427,34 @@ GAZ_DEV uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// The row is handled in units of one board cell (C bytes: a dword for Connect4, 16 bits otherwise), one load per unit.
+template <class G> struct CellUnit { typedef uint16_t type; };
+template <> struct CellUnit<Game<GAME_C4>> { typedef uint32_t type; };
+
 // order-independent 64-bit hash of the encoded row (each lane mixes the cells it owns, the wave adds)
 template <class G> GAZ_DEV uint64_t row_hash(const int8_t* row) {
+    typedef typename CellUnit<G>::type U;
+    static_assert(sizeof(U) == G::C, "one unit per cell");
+    const U* r = reinterpret_cast<const U*>(row);
     uint64_t h = 0;
-    for (int c = lane_id(); c < G::HW; c += WAVE) {
-        uint32_t v = 0;
-        for (int k = 0; k < G::C; ++k) v |= (uint32_t)(uint8_t)row[c * G::C + k] << (8 * k);
-        h += mix64(((uint64_t)(c + 1) << 32) | v);
-    }
+    for (int c = lane_id(); c < G::HW; c += WAVE) h += mix64(((uint64_t)(c + 1) << 32) | (uint64_t)r[c]);
     return wave_sum_u64(h);
 }
 
-// true: row g of nn_policy / nn_value now holds the cached outputs for row g of nn_in
-template <class G> GAZ_DEV bool cache_probe(const DevParams<G>& E, int g) {
+// entry holding the outputs for row g of nn_in, or null.  The caller reads policy / value straight from the entry.
+template <class G> GAZ_DEV const uint8_t* cache_probe(const DevParams<G>& E, int g) {
     using CL = CacheLayout<G>;
+    typedef typename CellUnit<G>::type U;
     const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
     const uint64_t h = mix64(row_hash<G>(row));
     const uint8_t* ent = E.cache + (size_t)((uint32_t)h & E.cache_mask) * (size_t)E.cache_stride;
     const uint32_t tag = (uint32_t)(h >> 32) | 1u;
-    if (uni(*reinterpret_cast<const uint32_t*>(ent)) != tag) return false;
+    if (uni(*reinterpret_cast<const uint32_t*>(ent)) != tag) return nullptr;
+    const U* r = reinterpret_cast<const U*>(row); const U* k = reinterpret_cast<const U*>(ent + CL::OFF_KEY);
     bool same = true;
-    for (int i = lane_id(); i < CL::ROWB; i += WAVE) same = same && (ent[CL::OFF_KEY + i] == (uint8_t)row[i]);
-    if (ballot(!same) != 0) return false;
-    const float* pol = reinterpret_cast<const float*>(ent + CL::OFF_POL);
-    for (int a = lane_id(); a < G::A; a += WAVE) E.nn_policy[(size_t)g * G::A + a] = pol[a];
-    if (lane_id() == 0) E.nn_value[g] = *reinterpret_cast<const float*>(ent + CL::OFF_VAL);
-    wave_sync();
-    return true;
+    for (int c = lane_id(); c < G::HW; c += WAVE) same = same && (k[c] == r[c]);
+    if (ballot(!same) != 0) return nullptr;
+    return ent;
 }
 
 // k_cache_insert body: game g's pending request was evaluated this wave -> store (row, outputs)
@@ -465,7 +468,9 @@ template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
     if (lane_id() == 0) prev = atomic_exch(&E.cache_lock[slot], E.cache_epoch);     // one writer per slot and wave
     if (uni(prev) == E.cache_epoch) return;
     uint8_t* ent = E.cache + (size_t)slot * (size_t)E.cache_stride;
-    for (int i = lane_id(); i < CL::ROWB; i += WAVE) ent[CL::OFF_KEY + i] = (uint8_t)row[i];
+    typedef typename CellUnit<G>::type U;
+    const U* r = reinterpret_cast<const U*>(row); U* k = reinterpret_cast<U*>(ent + CL::OFF_KEY);
+    for (int c = lane_id(); c < G::HW; c += WAVE) k[c] = r[c];
     float* pol = reinterpret_cast<float*>(ent + CL::OFF_POL);
     for (int a = lane_id(); a < G::A; a += WAVE) pol[a] = E.nn_policy[(size_t)g * G::A + a];
     if (lane_id() == 0) {
@@ -476,12 +481,14 @@ template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
 
 // K4 first half (+K3, K5): expand the next child of `node`.  Returns true if an evaluation is pending
 // (row g written), false if the simulation completed here (terminal parent created and backed up).
+// `staged`: puct_select left this node's header + child blocks in S.node (saves two dependent round trips)
 template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
-                                           int node, int depth) {
+                                           int node, int depth, bool staged) {
     NodeRef<G> pn = node_at(E, g, t, node);
-    const NodeHdr ph = *pn.hdr();
+    const NodeRef<G> ps = staged ? NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)} : pn;
+    const NodeHdr ph = *ps.hdr();
     const int slot = uni((int)ph.n_children);
-    const int action = uni((int)pn.act()[slot]);                       // popleft (MCTS.py:437)
+    const int action = uni((int)ps.act()[slot]);                       // popleft (MCTS.py:437)
     const int mover = -(int)uni((int)ph.player);
     copy_board<G>(S.board, pn.board());
     wave_sync();
@@ -527,22 +534,25 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
 }
 
 // K4 second half: policy/value row of the leaf -> child record, link into the parent, backup(-value, 1)
-template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
+// `fresh`: called in the launch that ran expand_pre (evaluation-cache hit): S.board and S.path are still the leaf's
+template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S,
+                                            const float* policy, const float* value_p, bool fresh) {
     const int node = gs.pend_parent, slot = gs.pend_slot, idx = gs.pend_node, depth = gs.pend_depth;
     NodeRef<G> nd = node_at(E, g, t, idx);
-    copy_board<G>(S.board, nd.board());
-    wave_sync();
+    if (!fresh) { copy_board<G>(S.board, nd.board()); wave_sync(); }
     const int n_legal = build_legal<G>(S.board, S.legal);
-    make_priors<G>(E, g, gs, ts, t, S, E.nn_policy + (size_t)g * G::A, n_legal);
+    make_priors<G>(E, g, gs, ts, t, S, policy, n_legal);
     write_children_from_scratch<G>(nd, S, n_legal);
     NodeRef<G> pn = node_at(E, g, t, node);
     if (lane_id() == 0) {
         nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0;
         pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1);
     }
-    const float value = E.nn_value[g];
-    const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
-    for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    const float value = *value_p;
+    if (!fresh) {
+        const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+        for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+    }
     wave_sync();
     backup<G>(E, g, t, ts, S.path, depth, -value, 1u);                 // MCTS.py:511
 }
@@ -710,12 +720,12 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
 
     if (uni(gs.pend_kind) == PEND_ROOT) {
         const int t = uni(gs.pend_tree);
-        root_post<G>(E, g, gs, trees[t], t, S);
+        root_post<G>(E, g, gs, trees[t], t, S, E.nn_policy + (size_t)g * G::A);
         if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo &= ~(1 << t); gs.n_evals += 1; }
         wave_sync();
     } else if (uni(gs.pend_kind) == PEND_EXPAND) {
         const int t = uni(gs.pend_tree);
-        expand_post<G>(E, g, gs, trees[t], t, S);
+        expand_post<G>(E, g, gs, trees[t], t, S, E.nn_policy + (size_t)g * G::A, E.nn_value + g, false);
         if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.sims_done += 1; gs.n_evals += 1; gs.n_sims += 1; gs.move_evals += 1; }
         wave_sync();
     }
@@ -737,8 +747,9 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             if (todo == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
             const int t = (todo & 1) ? 0 : 1;
             if (root_pre<G>(E, g, gs, trees[t], t, S)) {
-                if (E.cache && cache_probe<G>(E, g)) {                 // evaluation cache hit: the root is complete in this launch
-                    root_post<G>(E, g, gs, trees[t], t, S);
+                const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                if (hit) {                                             // evaluation cache hit: the root is complete in this launch
+                    root_post<G>(E, g, gs, trees[t], t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL));
                     if (lane_id() == 0) { gs.roots_todo &= ~(1 << t); gs.n_evals += 1; gs.n_hits += 1; }
                     wave_sync();
                     continue;
@@ -830,9 +841,11 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                 if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
             } else {
-                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth)) {
-                    if (!(E.cache && cache_probe<G>(E, g))) return;    // miss: the evaluator answers in the next launch
-                    expand_post<G>(E, g, gs, ts, t, S);                // hit: consume the cached outputs now
+                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth, kind == 0 && uni(gs.fully_visited) != 0)) {
+                    const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                    if (!hit) return;                                  // miss: the evaluator answers in the next launch
+                    expand_post<G>(E, g, gs, ts, t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
+                                   reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: consume the cached outputs now
                     if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                     wave_sync();
                 }
