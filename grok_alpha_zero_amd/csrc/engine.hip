@@ -39,6 +39,16 @@ template <class G> GAZ_KERNEL k_cache_insert(DevParams<G> E, int g0, int g1) {
     if (g < g1) cache_insert<G>(E, g);
 }
 
+// sqrt(pv) and the exploration factor of every parent visit count below PUCT_TABLE_N, computed by the code the kernel would run
+template <int UNUSED> GAZ_KERNEL_WIDE k_init_puct_table(double* table, double c_init, double c_base, int n) {
+#ifdef GAZ_HOST_EMU
+    for (int i = 0; i < n; ++i) { table[2 * i] = dsqrt((double)i); table[2 * i + 1] = puct_c_of((double)i, c_init, c_base); }
+#else
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { table[2 * i] = dsqrt((double)i); table[2 * i + 1] = puct_c_of((double)i, c_init, c_base); }
+#endif
+}
+
 template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
@@ -183,6 +193,15 @@ template <class G> struct EngineT : gaz_engine {
 
     ~EngineT() override {
         hipStreamSynchronize(stream);
+        if (E.prof) {                               // GAZ_TREE_PROF=1: phase cycles of the PUCT kernel, summed over games, to stderr
+            std::vector<unsigned long long> h((size_t)E.n_games * 8);
+            hipMemcpy(h.data(), E.prof, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < h.size(); ++i) t[i % 8] += h[i];
+            const char* nm[7] = {"consume", "select", "expand_pre", "cache_probe", "expand_post(hit)", "terminal backup", "whole launch"};
+            fprintf(stderr, "[tree prof] launches/game %.0f\n", (double)t[7] / E.n_games);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, "[tree prof] %-18s %8.0f cycles / game-launch (%.1f %%)\n", nm[k], (double)t[k] / (double)t[7], 100.0 * t[k] / t[6]);
+        }
         delete eval;
         for (void* p : allocs) hipFree(p);
         for (hipEvent_t e : ev) hipEventDestroy(e);
@@ -253,6 +272,17 @@ template <class G> struct EngineT : gaz_engine {
             E.cache_stride = CacheLayout<G>::SIZE; E.cache_mask = (uint32_t)(slots - 1); E.cache_epoch = 1;
             if (dalloc(&E.cache, slots * (size_t)E.cache_stride)) return 1;      // zeroed: tag 0 never matches (tags are odd)
             if (dalloc(&E.cache_lock, slots)) return 1;
+        }
+        if (getenv("GAZ_TREE_PROF") && atoi(getenv("GAZ_TREE_PROF"))) { if (dalloc(&E.prof, (size_t)n * 8)) return 1; }
+        if (!gumbel) {
+            double* tb = nullptr;
+            if (dalloc(&tb, (size_t)2 * PUCT_TABLE_N)) return 1;
+#ifdef GAZ_HOST_EMU
+            GAZ_LAUNCH(k_init_puct_table<0>, 1, 1, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
+#else
+            GAZ_LAUNCH(k_init_puct_table<0>, (PUCT_TABLE_N + 255) / 256, 256, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
+#endif
+            E.puct_table = tb;
         }
         if (dalloc(&E.stats, 8)) return 1;
         if (dalloc(&E.error, 4)) return 1;

@@ -59,8 +59,19 @@ template <class G> struct DevParams {
     // evaluation cache (0 = off): direct-mapped, entry = [tag u32][pad u32][state row, 8-byte padded][policy f32 x A][value f32]
     uint8_t* cache; uint32_t* cache_lock; uint32_t cache_mask, cache_epoch; int32_t cache_stride;
     unsigned long long* stats; // [8]: game_stats[0..5] (Self_Play.py:181-188), [6] waves, [7] spare
+    const double* puct_table;  // [PUCT_TABLE_N][2]: sqrt(pv), c_init + ln((pv + c_base + 1) / c_base)
+    unsigned long long* prof;  // diagnostic (GAZ_TREE_PROF=1): [n_games][8] shader-clock cycles per phase of the PUCT kernel, else null
     int32_t* error;            // first error code, 0 = none
 };
+
+// phase accounting of the PUCT kernel: 0 consume, 1 select, 2 expand_pre, 3 probe, 4 expand_post (hit), 5 terminal backup, 6 whole launch, 7 launches
+#ifdef GAZ_HOST_EMU
+#define GAZ_PROF(k, t0) do { } while (0)
+#define GAZ_PROF_NOW() 0ll
+#else
+#define GAZ_PROF_NOW() (E.prof ? (long long)clock64() : 0ll)
+#define GAZ_PROF(k, t0) do { if (E.prof && lane_id() == 0) E.prof[(size_t)g * 8 + (k)] += (unsigned long long)((long long)clock64() - (t0)); } while (0)
+#endif
 
 enum : int32_t { ERR_ARENA_FULL = 1, ERR_ROOT_NOT_EXPANDED = 2, ERR_PATH_OVERFLOW = 3, ERR_LOOP_GUARD = 4, ERR_BAD_SELECT = 5 };
 
@@ -200,11 +211,18 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
 
 // K1: argmax_i  Q_i + U_i over the node's n_actions children (expanded and not), float64 like numpy:
 //   U_i = (P_i * (sqrt(Np) / (N_i + 1))) * (c_init + ln((Np + c_base + 1) / c_base));  Q_i = f32(W_i / N_i) or W_i
+// The two factors that depend only on the parent's visit count come from a table filled at engine creation by the same code
+// (k_init_puct_table): a float64 log, a division and a square root are ~110 of the ~300 vector instructions of a level, and the
+// tree kernel is VALU-bound.
+constexpr int PUCT_TABLE_N = 16384;
+GAZ_DEV double puct_c_of(double pv, double c_init, double c_base) { return c_init + det::dlog((pv + c_base + 1.0) / c_base); }
+
 template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_actions, uint64_t parent_visits,
-                                              double c_init, double c_base) {
+                                              double c_init, double c_base, const double* table) {
     const double pv = (double)parent_visits;
-    const double s = dsqrt(pv);
-    const double c = c_init + det::dlog((pv + c_base + 1.0) / c_base);
+    double s, c;
+    if (table && parent_visits < (uint64_t)PUCT_TABLE_N) { s = table[2 * parent_visits]; c = table[2 * parent_visits + 1]; }
+    else { s = dsqrt(pv); c = puct_c_of(pv, c_init, c_base); }
     const uint32_t* N = nd.N(); const float* Wv = nd.W(); const float* P = nd.P();
     double best = 0.0; int bi = 0x7fffffff;
     for (int i = lane_id(); i < n_actions; i += WAVE) {
@@ -215,7 +233,7 @@ template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_action
         double sc = (double)q + u;
         if (bi == 0x7fffffff || sc > best) { best = sc; bi = i; }
     }
-    wave_argmax(best, bi);
+    wave_argmax(best, bi, n_actions);
     return uni(bi);
 }
 
@@ -401,7 +419,7 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
             wave_sync();
             return 1;
         }
-        const int best = best_puct_slot<G>(nd, n_actions, pv, E.c_init, E.c_base);
+        const int best = best_puct_slot<G>(nd, n_actions, pv, E.c_init, E.c_base, E.puct_table);
         if (best == n_children) { wave_sync(); return 0; }          // MCTS.py:217-218
         if (best > n_children) { set_error(E.error, ERR_BAD_SELECT); return -1; }
         S.path[depth].node = node; S.path[depth].slot = best; depth++;
@@ -718,6 +736,8 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
 template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, TreeState* trees) {
     using RL = RecLayout<G>;
 
+    const long long tp0 = GAZ_PROF_NOW();
+    if (E.prof && lane_id() == 0) E.prof[(size_t)g * 8 + 7] += 1;
     if (uni(gs.pend_kind) == PEND_ROOT) {
         const int t = uni(gs.pend_tree);
         root_post<G>(E, g, gs, trees[t], t, S, E.nn_policy + (size_t)g * G::A);
@@ -730,6 +750,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
         wave_sync();
     }
 
+    GAZ_PROF(0, tp0);
     int tree_only = 0;   // simulations completed in this launch without an evaluation
     for (int guard = 0; guard < 100000; ++guard) {
         const int phase = uni(gs.phase);
@@ -833,21 +854,32 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             if (tree_only >= E.max_tree_sims) return;                  // bound the launch's tail; resume next wave
             tree_only++;
             int node, depth; bool leaf_win = false; int kind;
+            const long long ts0 = GAZ_PROF_NOW();
             if (!uni(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
             else kind = puct_select<G>(E, g, gs, ts, t, S, node, depth, leaf_win);
+            GAZ_PROF(1, ts0);
             if (kind < 0) return;
             if (kind == 1) {                                           // terminal leaf: value 1 / 0, visits 1 (MCTS.py:573-575)
+                const long long tb0 = GAZ_PROF_NOW();
                 backup<G>(E, g, t, ts, S.path, depth, leaf_win ? 1.0f : 0.0f, 1u);
                 if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
+                GAZ_PROF(5, tb0);
             } else {
-                if (expand_pre<G>(E, g, gs, ts, t, S, node, depth, kind == 0 && uni(gs.fully_visited) != 0)) {
+                const long long te0 = GAZ_PROF_NOW();
+                const bool pending = expand_pre<G>(E, g, gs, ts, t, S, node, depth, kind == 0 && uni(gs.fully_visited) != 0);
+                GAZ_PROF(2, te0);
+                if (pending) {
+                    const long long tc0 = GAZ_PROF_NOW();
                     const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                    GAZ_PROF(3, tc0);
                     if (!hit) return;                                  // miss: the evaluator answers in the next launch
+                    const long long tx0 = GAZ_PROF_NOW();
                     expand_post<G>(E, g, gs, ts, t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                    reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: consume the cached outputs now
                     if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                     wave_sync();
+                    GAZ_PROF(4, tx0);
                 }
                 if (uni(*E.error)) return;
                 if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
@@ -926,11 +958,13 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
     GameState<G>* gsG = &E.games[g];
     TreeState* tsG = E.trees + (size_t)g * 2;
     if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); return; }
+    const long long tw0 = GAZ_PROF_NOW();
     copy_state_words(&L.gs, gsG); copy_state_words(&L.ts[0], &tsG[0]); copy_state_words(&L.ts[1], &tsG[1]);
     wave_sync();
     game_step_body<G>(E, g, S, L.gs, L.ts);
     wave_sync();
     copy_state_words(gsG, &L.gs); copy_state_words(&tsG[0], &L.ts[0]); copy_state_words(&tsG[1], &L.ts[1]);
+    GAZ_PROF(6, tw0);
 }
 
 }  // namespace gaz

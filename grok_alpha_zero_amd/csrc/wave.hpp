@@ -76,10 +76,13 @@ template <class T> GAZ_DEV T atomic_exch(T* p, T v) { return atomicExch(p, v); }
 namespace gaz {
 // wave argmax over (score, index): largest score wins, ties -> LOWEST index (np.argmax semantics,
 // MCTS.py:191).  Lanes holding no candidate pass idx = INT32_MAX.
-GAZ_DEV void wave_argmax(double& score, int& idx) {
+// `span`: candidates live in lanes [0, span) only (wave-uniform; span = 64 reduces the whole wave).  Lane 0 ends up with the
+// result either way; the butterfly below span leaves it in every lane < span, callers broadcast with uni().
+GAZ_DEV void wave_argmax(double& score, int& idx, int span = 64) {
 #ifndef GAZ_HOST_EMU
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+    int m0 = 32;
+    if (span <= 8) m0 = 4; else if (span <= 16) m0 = 8; else if (span <= 32) m0 = 16;
+    for (int m = m0; m >= 1; m >>= 1) {
         double os = shfl_xor(score, m);
         int oi = shfl_xor(idx, m);
         bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || os > score || (os == score && oi < idx));
