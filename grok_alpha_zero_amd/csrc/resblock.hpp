@@ -448,4 +448,132 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
     RB_STAMP(23);
 }
 
+// ---- k_conv_heads: the first convolution of both heads (Connect4/Build_Model.py:41,62: two 3x3 convs 128 -> 8, fused into one
+// 128 -> 16 GEMM, padded to a 32-column MFMA tile) in the style of k_resblock3: image by LDS-DMA, weights from L2 into a register
+// ring, no barrier in the tap loop, two 256-thread workgroups per CU.  A wave owns 64 rows x the 32 columns; the epilogue applies
+// the flat-feature BN + ReLU of each head and writes fp32 [B][HW * 8] per head (EPI = 1 of k_conv3x3, which this replaces: that
+// kernel spent 40 us per forward in per-tap barriers and weight DMA for 6 us of MFMA work).
+struct HeadsConvArgs {
+    const bf16_t* in; const bf16_t* wgt;          // [M][128]; fragment order [9][8 k-steps][2][32 cout][8]
+    const float* bias;                            // [32]
+    const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft;   // [HW * 8] flat BN scale / shift
+    float* p_feat; float* v_feat;                 // [B][HW * 8]
+    int M, H, W;
+};
+constexpr int HC_ROWS = 256;
+constexpr size_t hc_lds_bytes() { return (size_t)(HC_ROWS + 2 * CONV_HALO_MAX + 1) * 256; }
+
+__global__ __launch_bounds__(RB3_THREADS, 2) void k_conv_heads(HeadsConvArgs a) {
+    constexpr int SLOTS = 16, TM = 2, KS = 8, BN = 32, BSL = BN * SLOTS;
+    constexpr int AROWS = HC_ROWS + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1;
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int h = a.W + 1, HW = a.H * a.W;
+    const long m0 = (long)blockIdx.x * HC_ROWS;
+    const uint4* in4 = reinterpret_cast<const uint4*>(a.in);
+
+    // image row q <-> global row m0 - h + q
+    const int n_aslots = (HC_ROWS + 2 * h) * SLOTS;
+    for (int base = wave * 64; base < n_aslots; base += RB3_THREADS) {
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+        long gr = m0 - h + lr;
+        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
+    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, 9 * BSL * 16, 0x00020000);
+    const int bvo = (lhi * BN + l31) * 16;
+    auto ldb = [&](int tap, int ks) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, (tap * BSL + ks * 2 * BN) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    // Only two MFMAs separate consecutive k-steps here, so the ring is three taps (24 k-steps, ~1500 MFMA cycles) deep.
+    constexpr int RING = 24;
+    uint4 bfr[RING];
+#pragma unroll
+    for (int g = 0; g < RING; ++g) bfr[g] = ldb(g / KS, g % KS);
+
+    int lrow[TM]; unsigned vmask[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wave * TM + tm) * 32 + l31;
+        const long gr = m0 + lrow[tm];
+        unsigned mm = 0;
+        if (gr < a.M) {
+            const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
+            }
+        }
+        vmask[tm] = mm;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
+    __syncthreads();                                // image landed (the only barrier)
+
+#pragma unroll 1
+    for (int t3 = 0; t3 < 3; ++t3) {                // three taps per iteration: ring slot = k-step index within the triple
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap = t3 * 3 + tt;
+            const int off = (t3 - 1) * a.W + (tt - 1);
+            int abase[TM], axor[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bool ok = (vmask[tm] >> tap) & 1u;
+                const int ar = ok ? lrow[tm] + h + off : ZROW;
+                abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+            }
+            uint4 afr[2][TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                }
+                const bf16x8 bf = *reinterpret_cast<bf16x8*>(&bfr[tt * KS + ks]);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf, acc[tm], 0, 0, 0);
+                const int ntap = tap + 3 < 9 ? tap + 3 : tap;           // the last three taps re-read themselves
+                bfr[tt * KS + ks] = ldb(ntap, ks);
+            }
+        }
+    }
+    // columns 0-7 policy conv, 8-15 value conv, the rest padding; C/D layout: col = l31, row = (r & 3) + 8 (r >> 2) + 4 lhi
+    if (l31 >= 16) return;
+    const float tA = a.bias[l31];
+    const float* __restrict__ fs = l31 < 8 ? a.p_fs : a.v_fs; const float* __restrict__ ft = l31 < 8 ? a.p_ft : a.v_ft;
+    float* __restrict__ feat = l31 < 8 ? a.p_feat : a.v_feat;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        // all 32 BN parameters first, then the stores: a load behind a store through an unrelated pointer is not hoisted, and
+        // the loop would pay one L2 round trip per output
+        float sc[16], sh[16]; size_t o[16]; bool ok[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wave * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const long gr = m0 + row;
+            ok[r] = gr < a.M;
+            const unsigned g32 = ok[r] ? (unsigned)gr : 0u;
+            const unsigned b = g32 / (unsigned)HW; const int cell = (int)(g32 - b * (unsigned)HW), f = cell * 8 + (l31 & 7);
+            sc[r] = fs[f]; sh[r] = ft[f]; o[r] = (size_t)b * (HW * 8) + f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) feat[o[r]] = fmaxf((acc[tm][r] + tA) * sc[r] + sh[r], 0.0f);
+    }
+}
+
 }  // namespace gaz
