@@ -130,6 +130,8 @@ GAZ_DEV double gamma(const Event& e, uint32_t lane, double alpha) {
         v = v * v * v;
         U4 r = draw(e, lane, attempt++);
         double u = u_open(r.x, r.y);
+        const double x2 = x * x;                     // squeeze (same accepted pairs as the log test, see oracle/gaz_det.h)
+        if (u < 1.0 - 0.0331 * (x2 * x2)) return (d * v) * boost;
         if (dlog(u) < ((0.5 * x) * x + d) - d * v + d * dlog(v)) return (d * v) * boost;
     }
 }
