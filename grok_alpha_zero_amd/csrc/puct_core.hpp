@@ -150,7 +150,7 @@ template <class G> GAZ_DEV int terminal_probe(const int8_t* board, const uint8_t
     int nt = 0;
     // pass 1: wins (descending), pass 2: draws (descending)
     any_win = false;
-    for (int pass = 0; pass < (G::DRAWS ? 2 : 1); ++pass) {
+    for (int pass = 0; pass < ((G::DRAWS && empties == 1) ? 2 : 1); ++pass) {   // a draw needs the last empty cell (wave-uniform)
         for (int base = ((n_legal - 1) / WAVE) * WAVE; base >= 0; base -= WAVE) {
             int i = base + lane_id();
             bool hit = false;
@@ -182,12 +182,19 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
         int max_length = n_hist - 1; if (max_length > 3) max_length = 3; if (max_length < 0) max_length = 0;
         int rem[3] = {-1, -1, -1};
         for (int i = 0; i < max_length; ++i) {      // y = min(where(prev_board[:, x] != 0)), then clear it
-            int x = hist3[i];
+            const int x = hist3[i];
+#ifdef GAZ_HOST_EMU
             int y = 0;
             for (; y < 6; ++y) {
                 int c = y * 7 + x;
                 if (board[c] != 0 && c != rem[0] && c != rem[1] && c != rem[2]) break;
             }
+#else
+            // lanes 0..5 look at one row each; the topmost occupied, not yet removed cell is the lowest set bit (6 = none)
+            const int c = (lane_id() < 6 ? lane_id() : 0) * 7 + x;
+            const uint64_t occ = ballot(lane_id() < 6 && board[c] != 0 && c != rem[0] && c != rem[1] && c != rem[2]);
+            const int y = occ ? ffsll0(occ) : 6;
+#endif
             rem[i] = y * 7 + x;
         }
         for (int c = lane_id(); c < G::HW; c += WAVE) {
