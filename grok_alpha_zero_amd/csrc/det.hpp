@@ -148,8 +148,17 @@ GAZ_DEV double gumbel(const Event& e, uint32_t lane) { U4 r = draw(e, lane, 0); 
 template <class T>
 GAZ_DEV T np_sum_block(const T* a, int n) {   // n <= 128
     if (n < 8) {
+        // every caller's array has at least 8 elements: seven independent reads, then the additions in numpy's order
+        // (a dependent read -> add loop costs one LDS round trip per element)
+        const T v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = a[4], v5 = a[5], v6 = a[6];
         T res = (T)0;
-        for (int i = 0; i < n; ++i) res = res + a[i];
+        if (n > 0) res = res + v0;
+        if (n > 1) res = res + v1;
+        if (n > 2) res = res + v2;
+        if (n > 3) res = res + v3;
+        if (n > 4) res = res + v4;
+        if (n > 5) res = res + v5;
+        if (n > 6) res = res + v6;
         return res;
     }
     T r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];

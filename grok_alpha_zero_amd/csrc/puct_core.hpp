@@ -256,8 +256,16 @@ template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const 
         det::Event e = make_event(E, g, gs, ts, tree, det::P_DIRICHLET);
         for (int i = lane_id(); i < n_legal; i += WAVE) S.gam[i] = det::gamma(e, (uint32_t)i, E.alpha);
         wave_sync();
-        double gs_sum = 0.0;
-        for (int i = 0; i < n_legal; ++i) gs_sum = gs_sum + S.gam[i];    // sequential, same in every lane
+        double gs_sum = 0.0;                                             // sequential, same in every lane
+        if (n_legal <= 8) {                                              // S.gam has >= 8 elements: batch the reads
+            double gv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gv[i] = S.gam[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i < n_legal) gs_sum = gs_sum + gv[i];
+        } else {
+            for (int i = 0; i < n_legal; ++i) gs_sum = gs_sum + S.gam[i];
+        }
         for (int i = lane_id(); i < n_legal; i += WAVE) {
             float p = S.pri[i] / sum;
             float a = E.one_minus_eps * p;
@@ -268,10 +276,23 @@ template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const 
         for (int i = lane_id(); i < n_legal; i += WAVE) S.pri[i] = S.pri[i] / sum;
     }
     wave_sync();
-    for (int i = lane_id(); i < n_legal; i += WAVE) {     // rank sort
-        float v = S.pri[i]; int rank = 0;
-        for (int j = 0; j < n_legal; ++j) { float o = S.pri[j]; rank += (o > v) || (o == v && j > i); }
-        S.sact[rank] = S.legal[i]; S.spri[rank] = v;
+    if (n_legal <= 8) {                                   // rank sort, small node: the eight priors in registers first
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = S.pri[j];
+        const int i = lane_id();
+        if (i < n_legal) {
+            const float v = S.pri[i]; int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += (j < n_legal) && ((pv[j] > v) || (pv[j] == v && j > i));
+            S.sact[rank] = S.legal[i]; S.spri[rank] = v;
+        }
+    } else {
+        for (int i = lane_id(); i < n_legal; i += WAVE) {
+            float v = S.pri[i]; int rank = 0;
+            for (int j = 0; j < n_legal; ++j) { float o = S.pri[j]; rank += (o > v) || (o == v && j > i); }
+            S.sact[rank] = S.legal[i]; S.spri[rank] = v;
+        }
     }
     wave_sync();
 }
