@@ -71,8 +71,16 @@ template <class G> GAZ_DEV NodeRef<G> g_stage_node(const DevParams<G>& E, int g,
 
 // softmax in float64 over S.gam[0..n): x <- exp(x - max) / np.sum(...)   (MCTS_Gumbel.py:82-88)
 template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
-    double mx = S.gam[0];
-    for (int i = 1; i < n; ++i) { double v = S.gam[i]; if (v > mx) mx = v; }       // uniform
+    double mx = S.gam[0];                                                           // uniform
+    if (n <= 8) {                                                                   // small node: the reads in one batch
+        double gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gv[i] = S.gam[i];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (i < n && gv[i] > mx) mx = gv[i];
+    } else {
+        for (int i = 1; i < n; ++i) { double v = S.gam[i]; if (v > mx) mx = v; }
+    }
     wave_sync();
     const double c = -mx;
     for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = det::dexp(S.gam[i] + c);
@@ -88,8 +96,16 @@ template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
 template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S, uint32_t& N_b_out,
                                            uint64_t& sumv_out) {
     const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P();
-    uint32_t nb = 0; uint64_t sumv = 0;
-    for (int i = 0; i < n; ++i) { uint32_t v = N[i]; if (v > nb) nb = v; sumv += v; }              // uniform
+    uint32_t nb = 0; uint64_t sumv = 0;                                                              // uniform
+    if (n <= 8) {
+        uint32_t nv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nv[i] = N[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < n) { if (nv[i] > nb) nb = nv[i]; sumv += nv[i]; }
+    } else {
+        for (int i = 0; i < n; ++i) { uint32_t v = N[i]; if (v > nb) nb = v; sumv += v; }
+    }
     for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)L[i];
     wave_sync();
     softmax_inplace<G>(S, n);
@@ -114,8 +130,16 @@ template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<
         S.spri[i] = N[i] > 0 ? S.aux[i] : vmix;                                                   // completed_q
     }
     wave_sync();
-    float mn = S.spri[0], mx = S.spri[0];
-    for (int i = 1; i < n; ++i) { float v = S.spri[i]; if (v < mn) mn = v; if (v > mx) mx = v; }   // uniform
+    float mn = S.spri[0], mx = S.spri[0];                                                            // uniform
+    if (n <= 8) {
+        float sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = S.spri[i];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (i < n) { if (sv[i] < mn) mn = sv[i]; if (sv[i] > mx) mx = sv[i]; }
+    } else {
+        for (int i = 1; i < n; ++i) { float v = S.spri[i]; if (v < mn) mn = v; if (v > mx) mx = v; }
+    }
     const float den = (mx - mn) > F32_EPS ? (mx - mn) : F32_EPS;
     const double sg = (E.c_visit + (double)nb) * E.c_scale;
     wave_sync();

@@ -280,8 +280,7 @@ template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const 
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) pv[j] = S.pri[j];
-        const int i = lane_id();
-        if (i < n_legal) {
+        for (int i = lane_id(); i < n_legal; i += WAVE) {
             const float v = S.pri[i]; int rank = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rank += (j < n_legal) && ((pv[j] > v) || (pv[j] == v && j > i));
