@@ -46,7 +46,7 @@ template <class T> inline T atomic_exch(T* p, T v) { T o = *p; *p = v; return o;
 // one wavefront per workgroup.  GAZ_TREE_WPE pins the waves per SIMD the register allocator aims for (4 -> 128 VGPRs with
 // spills to scratch, 3 -> 168, 2 -> no spills); see DESIGN.md for the measured choice.
 #ifndef GAZ_TREE_WPE
-#define GAZ_TREE_WPE 3                             // measured (tools/tree_sweep.sh): 0.074 / 0.080 / 0.083 ms per PUCT wave at 3 / 2 / 4
+#define GAZ_TREE_WPE 3                             // measured: 0.074 / 0.080 / 0.083 ms per PUCT wave at 3 / 2 / 4
 #endif
 #define GAZ_KERNEL __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAZ_TREE_WPE, GAZ_TREE_WPE))) void
 #define GAZ_KERNEL_WIDE __global__ void               // kernels launched with more than one wavefront per workgroup
