@@ -25,6 +25,7 @@ struct ResBlockArgs {
     const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
     const float* b2;                              // conv2 bias
     int M, H, W;
+    int halo, tile_rows;                          // k_resblock3: W + 1 and 64 TM - 2 (W + 1); or 0 and k * H * W when a tile is k whole boards
     unsigned long long* stamps;                   // diagnostic: [workgroup][RB_STAMPS]: 32 wall-clock ticks (100 MHz) + 32 shader-clock counts of wave 0, or null
 };
 
@@ -247,7 +248,9 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
-    const int h = a.W + 1, HW = a.H * a.W, bmo = ROWS - 2 * h;
+    // halo mode: h = W + 1 rows of context on both sides, conv1 recomputes them; board-aligned mode (tile = whole boards): every
+    // in-board tap stays inside the tile and the out-of-board ones are masked, so no halo is loaded or recomputed at all (h = 0)
+    const int h = a.halo, HW = a.H * a.W, bmo = a.tile_rows;
     const long m0 = (long)blockIdx.x * bmo;
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
     const int col0 = wn * 64 + l31;                 // + 32 * tn

@@ -31,18 +31,25 @@ static bf16_t f2bf_host(float f) {
     return (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// k_resblock3 launch: tile height 64 * TM with the least (rounds of 2 workgroups x n_cus) x TM, ties to the taller tile
-static int rb3_pick_tm(int M, int W, int n_cus) {
-    int tm = 3; double best = 1e30;
-    for (int c = 2; c <= 4; ++c) {
-        const int bm = 64 * c - 2 * (W + 1); const long nt = (M + bm - 1) / bm;
-        const double cost = (double)((nt + 2 * n_cus - 1) / (2 * n_cus)) * c;
-        if (cost <= best) { best = cost; tm = c; }
-    }
-    return tm;
+// k_resblock3 tiling: tile height 64 * TM, either with a halo (valid rows 64 TM - 2 (W + 1), conv1 recomputes the halo) or
+// board-aligned (k = floor(64 TM / HW) whole boards per tile, no halo).  Cost = rounds of (2 workgroups x n_cus) x TM; ties go
+// to the halo tiling (more valid rows per tile), then to the taller tile.
+struct Rb3Plan { int tm, halo, tile_rows; };
+static Rb3Plan rb3_plan(int M, int H, int W, int n_cus) {
+    Rb3Plan best{3, W + 1, 64 * 3 - 2 * (W + 1)}; double best_cost = 1e30;
+    for (int aligned = 0; aligned < 2; ++aligned)
+        for (int c = 2; c <= 4; ++c) {
+            const int rows = aligned ? (64 * c / (H * W)) * (H * W) : 64 * c - 2 * (W + 1);
+            if (rows <= 0) continue;
+            const long nt = (M + rows - 1) / rows;
+            const double cost = (double)((nt + 2 * n_cus - 1) / (2 * n_cus)) * c;
+            if (cost < best_cost || (cost == best_cost && !aligned)) { best_cost = cost; best = Rb3Plan{c, aligned ? 0 : W + 1, rows}; }
+        }
+    return best;
 }
-static void rb3_launch(hipStream_t s, const ResBlockArgs& r, int tm, int ring) {
-    const int bmo = 64 * tm - 2 * (r.W + 1), nwg = (r.M + bmo - 1) / bmo;
+static void rb3_launch(hipStream_t s, ResBlockArgs r, const Rb3Plan& p, int ring) {
+    r.halo = p.halo; r.tile_rows = p.tile_rows;
+    const int nwg = (r.M + p.tile_rows - 1) / p.tile_rows, tm = p.tm;
     if (tm == 2 && ring == 4) hipLaunchKernelGGL((k_resblock3<2, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
     else if (tm == 2) hipLaunchKernelGGL((k_resblock3<2, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<2>(), s, r);
     else if (tm == 3 && ring == 4) hipLaunchKernelGGL((k_resblock3<3, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
@@ -560,16 +567,15 @@ struct ResNetEvaluator : Evaluator {
             static const int rbv = getenv("GAZ_RB") ? atoi(getenv("GAZ_RB")) : 3;
             static const int rb_tm = getenv("GAZ_RB_TM") ? atoi(getenv("GAZ_RB_TM")) : 0;
             static const int rb_ring = getenv("GAZ_RB_RING") ? atoi(getenv("GAZ_RB_RING")) : 8;
-            // k_resblock3: tile height 64 * TM; take the TM with the least (rounds of 512 workgroups) x (tile cost ~ TM)
-            int tm = rb_tm;
-            if (rbv == 3 && tm == 0) tm = rb3_pick_tm(M, W, n_cus);
-            const int bmo = (rbv == 3 ? 64 * tm : RB_ROWS) - 2 * (W + 1);
+            Rb3Plan plan = rb3_plan(M, H, W, n_cus);
+            if (rb_tm) plan = Rb3Plan{rb_tm, W + 1, 64 * rb_tm - 2 * (W + 1)};
+            const int bmo = rbv == 3 ? plan.tile_rows : RB_ROWS - 2 * (W + 1);
             const size_t lds = conv_lds_bytes<128, 128, 256, 1>();
             const int nwg = (M + bmo - 1) / bmo;
             static const char* stamp_path = getenv("GAZ_RB_STAMPS");       // diagnostic: phase stamps of one launch -> file
             const bool stamp = stamp_path && i == 1 && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * RB_STAMPS * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * RB_STAMPS * 8, s); }
-            if (rbv == 3) rb3_launch(s, r, tm, rb_ring);
+            if (rbv == 3) rb3_launch(s, r, plan, rb_ring);
             else hipLaunchKernelGGL(k_resblock, dim3(nwg), dim3(RB_THREADS), lds, s, r);
             if (stamp) {
                 std::vector<unsigned long long> hst((size_t)nwg * RB_STAMPS);
@@ -783,7 +789,8 @@ struct GenericEvaluator : Evaluator {
                 r.xin = cur; r.xout = cur == X ? Hh : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
                 r.s1 = g(b + ".bn1.scale"); r.t1 = g(b + ".bn1.shift"); r.s2 = g(b + ".conv1.scale"); r.t2 = g(b + ".conv1.shift");
                 r.b2 = g(b + ".conv2.bias"); r.M = M; r.H = H; r.W = W;
-                rb3_launch(s, r, rb3_pick_tm(M, W, n_cus), 8);
+                const Rb3Plan plan = rb3_plan(M, H, W, n_cus);
+                rb3_launch(s, r, plan, plan.tm == 4 ? 4 : 8);
                 cur = r.xout; fused_blocks++;
                 if (last) hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("p.bn0.scale"), g("p.bn0.shift"), Aa, (long)M * F / 8, F);
                 continue;
