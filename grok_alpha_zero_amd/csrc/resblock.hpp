@@ -579,4 +579,205 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_conv_heads(HeadsConvArgs a) 
     }
 }
 
+// ---- k_block0: the FIRST residual block of the Gomoku network (Gomoku/Build_Model.py: 256 stem channels -> num_filters, so the
+// block has a 1x1 projection on its skip path, Net/ResNet/ResNet_Block.py:21-33) in the k_resblock3 structure:
+//     x_out = Conv3x3_2( relu(bn2( Conv3x3_1(a0) )) ) + Conv1x1_proj(x0)      a0 = relu(bn1(x0)) comes from the stem kernel
+// The 256-channel operands pass through the 128-channel LDS image in two halves: 29 weight slices of K = 128 in one array —
+// conv1 low half (9 taps), conv1 high half (9), conv2 (9), projection low / high (centre tap only) — walked by the same
+// register ring; the image is reloaded by LDS-DMA between the phases (5 loads instead of 1, the price of not writing
+// h = conv1(...) and proj(x0) to HBM and back: 873 us for three kernels before).
+struct Block0Args {
+    const bf16_t* a0; const bf16_t* x0;           // [M][256] pre-activated / raw stem output
+    bf16_t* xout;                                 // [M][128]
+    const bf16_t* w;                              // 29 slices [8 k-steps][2][128 cout][8] (fragment order)
+    const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
+    const float* b2; const float* bp;             // conv2 bias, projection bias
+    int M, H, W, halo, tile_rows;
+};
+
+template <int TM, int RING>
+__global__ __launch_bounds__(RB3_THREADS, 2) void k_block0(Block0Args a) {
+    constexpr int BN = 128, SLOTS = 16, TN = 2, KS = 8, ROWS = rb3_rows<TM>(), NSL = 29;
+    constexpr int AROWS = ROWS + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1, BSL = BN * SLOTS;
+    static_assert(KS % RING == 0, "ring slot must not depend on the slice");
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int h = a.halo, HW = a.H * a.W, bmo = a.tile_rows;
+    const long m0 = (long)blockIdx.x * bmo;
+    const int col0 = wn * 64 + l31;
+
+    // image row q <-> global row row0 + q of channels [128 half, 128 half + 128) of a 256-channel tensor
+    auto load_image = [&](const bf16_t* src, int half, long row0, int nrows) {
+        const uint4* in4 = reinterpret_cast<const uint4*>(src);
+        for (int base = wave * 64; base < nrows * SLOTS; base += RB3_THREADS) {
+            const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+            long gr = row0 + lr;
+            gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
+            __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * (2 * SLOTS) + half * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
+        }
+    };
+    load_image(a.a0, 0, m0 - 2 * h, ROWS + 2 * h);
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, NSL * BSL * 16, 0x00020000);
+    const int bvo = (lhi * BN + col0) * 16;
+    auto ldb = [&](int slice, int ks, int tn) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, ((slice * BSL) + ks * 2 * BN + tn * 32) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    uint4 bfr[RING][TN];
+#pragma unroll
+    for (int g = 0; g < RING; ++g)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = ldb(0, g, tn);
+    float ps2[TN], pt2[TN], pb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { ps2[tn] = a.s2[col0 + tn * 32]; pt2[tn] = a.t2[col0 + tn * 32]; pb[tn] = a.b2[col0 + tn * 32] + a.bp[col0 + tn * 32]; }
+
+    int lrow[TM]; unsigned vmask[TM];               // bits 0-8: conv1 taps, 9-17: conv2 taps, 18: the row itself (projection)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wm * TM + tm) * 32 + l31;
+        unsigned mm = 0;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const long gr = m0 + lrow[tm] - (which == 0 ? h : 0);
+            if (gr >= 0 && gr < a.M) {
+                const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << (which * 9 + t);
+                }
+                if (which == 1) mm |= 1u << 18;
+            }
+        }
+        vmask[tm] = mm;
+    }
+
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    };
+    // slices [s0, s0 + n): slice s uses tap offset taps9 ? (s - s0) : centre, validity bit mbit0 (+ tap index when taps9)
+    auto run_slices = [&](int s0, int n, bool taps9, int mbit0) {
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) {
+            const int sl = s0 + i, nsl = sl + 1 < NSL ? sl + 1 : sl;
+            const int tap = taps9 ? i : 4, ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+            const int mbit = taps9 ? mbit0 + i : mbit0;
+            int abase[TM], axor[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bool ok = (vmask[tm] >> mbit) & 1u;
+                const int ar = ok ? lrow[tm] + h + off : ZROW;
+                abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+            }
+            uint4 afr[2][TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                }
+                bf16x8 bf[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
+                if (ks + RING < KS) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(nsl, ks + RING - KS, tn);
+                }
+            }
+        }
+    };
+
+    zero_acc();
+    __syncthreads();                                // a0 low half landed
+    run_slices(0, 9, true, 0);                      // conv1, input channels 0-127
+    __syncthreads();                                // every wave is done with this image
+    load_image(a.a0, 1, m0 - 2 * h, ROWS + 2 * h);
+    __syncthreads();
+    run_slices(9, 9, true, 0);                      // conv1, input channels 128-255
+    __syncthreads();
+    {   // h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
+        bf16_t* Hs = reinterpret_cast<bf16_t*>(As);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = col0 + tn * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float v = fmaxf(acc[tm][tn][r] * ps2[tn] + pt2[tn], 0.0f);
+                    Hs[row * 128 + ((((col >> 3) ^ (row & 15)) << 3) | (col & 7))] = (bf16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+                }
+            }
+    }
+    __syncthreads();
+    zero_acc();
+    run_slices(18, 9, true, 9);                     // conv2 over h
+    __syncthreads();
+    load_image(a.x0, 0, m0 - h, ROWS + h);          // image row q <-> global m0 - h + q, like the h image
+    __syncthreads();
+    run_slices(27, 1, false, 18);                   // + projection of x0, channels 0-127
+    __syncthreads();
+    load_image(a.x0, 1, m0 - h, ROWS + h);
+    __syncthreads();
+    run_slices(28, 1, false, 18);                   // + projection of x0, channels 128-255
+    __syncthreads();
+
+    // epilogue, half the rows at a time through an fp32 tile over the image region: + conv2 bias + projection bias
+    constexpr int CT = BN + 4, HR = ROWS / 2;
+    float* Ct = reinterpret_cast<float*>(lds);
+    static_assert((size_t)HR * CT * 4 <= (size_t)AROWS * SLOTS * 16, "epilogue tile must fit in the image region");
+    const int chunk = tid % 16, r0 = tid / 16;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        Ct[row * CT + col0 + tn * 32] = acc[tm][tn][r] + pb[tn];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2 * TM; ++q) {
+            const int rl = r0 + q * (RB3_THREADS / 16), row = pass * HR + rl;
+            const long gr = m0 + row;
+            if (row < bmo && gr < a.M) {
+                const float4 c0 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&Ct[rl * CT + chunk * 8 + 4]);
+                *reinterpret_cast<uint4*>(a.xout + (size_t)gr * BN + chunk * 8) =
+                    make_uint4(pack_bf16(c0.x, c0.y), pack_bf16(c0.z, c0.w), pack_bf16(c1.x, c1.y), pack_bf16(c1.z, c1.w));
+            }
+        }
+        if (pass == 0) __syncthreads();
+    }
+}
+
 }  // namespace gaz
