@@ -48,9 +48,6 @@ struct ConvArgs {
     const float* scaleB;     // second output: relu(out1*scaleB + shiftB); out2 null = none
     const float* shiftB;
     bf16_t* out2;
-    // heads epilogue (EPI == 1): relu((acc + shiftA[c]) * fs[cell*8+c] + ft[cell*8+c]) -> f32 [B][HW*8] per head
-    const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft;
-    float* p_feat; float* v_feat;
     int M, H, W;
 };
 
@@ -180,7 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (EPI == 0) {
+    static_assert(EPI == 0, "one epilogue");
+    {
         constexpr int CT = BN + 4;
         float* Ct = reinterpret_cast<float*>(lds);  // [BM][BN + 4] fp32 over the (now idle) image + slices
         static_assert((size_t)BM * CT * 4 <= conv_lds_bytes<CIN, BN, BM, KSPLIT>(), "epilogue tile must fit");
@@ -234,27 +232,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * OCC + 3) / 4) void k_conv3
                     make_uint4(pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]), pack_bf16(w[4], w[5]), pack_bf16(w[6], w[7]));
             }
         }
-    } else {
-        // heads: only columns 0-15 are real (0-7 policy conv, 8-15 value conv); flat-feature BN + ReLU, fp32 out
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = (wn * TN + tn) * 32 + l31;
-                if (col >= 16) continue;
-                const float tA = a.shiftA ? a.shiftA[col] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const long gr = m0 + row;
-                    if (gr >= a.M) continue;
-                    const unsigned gr32 = (unsigned)gr;                       // M < 2^31 (host-checked): 32-bit division
-                    const unsigned b = gr32 / (unsigned)HW; const int cell = (int)(gr32 - b * (unsigned)HW), f = cell * 8 + (col & 7);
-                    const float v = acc[tm][tn][r] + tA;
-                    if (col < 8) a.p_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.p_fs[f] + a.p_ft[f], 0.0f);
-                    else a.v_feat[(size_t)b * (HW * 8) + f] = fmaxf(v * a.v_fs[f] + a.v_ft[f], 0.0f);
-                }
-            }
     }
 }
 

@@ -594,24 +594,11 @@ struct ResNetEvaluator : Evaluator {
                        last ? nullptr : f32[nb + ".bn1.scale"], last ? nullptr : f32[nb + ".bn1.shift"], last ? nullptr : Aa, M);
         }
         if (timing) hipEventRecord(e1, s);
-        {
-            ConvArgs a; memset(&a, 0, sizeof(a));
-            a.in = cur; a.wgt = b16["heads.conv.w"]; a.shiftA = f32["heads.conv.bias"]; a.M = M; a.H = H; a.W = W;
-            a.p_fs = f32["p.bn0.scale"]; a.p_ft = f32["p.bn0.shift"]; a.v_fs = f32["v.bn0.scale"]; a.v_ft = f32["v.bn0.shift"];
-            a.p_feat = pfeat; a.v_feat = vfeat;
-            static const int hv = getenv("GAZ_HEADS_VARIANT") ? atoi(getenv("GAZ_HEADS_VARIANT")) : 2;
-            if (hv == 2) {
-                HeadsConvArgs hc; hc.in = cur; hc.wgt = b16["heads.conv.w"]; hc.bias = f32["heads.conv.bias"];
-                hc.p_fs = a.p_fs; hc.p_ft = a.p_ft; hc.v_fs = a.v_fs; hc.v_ft = a.v_ft; hc.p_feat = pfeat; hc.v_feat = vfeat;
-                hc.M = M; hc.H = H; hc.W = W;
-                hipLaunchKernelGGL(k_conv_heads, dim3((M + HC_ROWS - 1) / HC_ROWS), dim3(RB3_THREADS), hc_lds_bytes(), s, hc);
-            } else if (hv == 0) {
-                const size_t lds = conv_lds_bytes<128, 32, 256, 1>();
-                hipLaunchKernelGGL((k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), dim3((M + 255) / 256), dim3(512), lds, s, a);
-            } else {
-                const size_t lds = conv_lds_bytes<128, 32, 128, 1>();
-                hipLaunchKernelGGL((k_conv3x3<128, 32, 128, 4, 1, 1, 1, 1, 2, 1>), dim3((M + 127) / 128), dim3(256), lds, s, a);
-            }
+        {   // first conv of both heads + flat BN + ReLU (k_conv_heads)
+            HeadsConvArgs hc; hc.in = cur; hc.wgt = b16["heads.conv.w"]; hc.bias = f32["heads.conv.bias"];
+            hc.p_fs = f32["p.bn0.scale"]; hc.p_ft = f32["p.bn0.shift"]; hc.v_fs = f32["v.bn0.scale"]; hc.v_ft = f32["v.bn0.shift"];
+            hc.p_feat = pfeat; hc.v_feat = vfeat; hc.M = M; hc.H = H; hc.W = W;
+            hipLaunchKernelGGL(k_conv_heads, dim3((M + HC_ROWS - 1) / HC_ROWS), dim3(RB3_THREADS), hc_lds_bytes(), s, hc);
         }
         const int F = HW * 8;
         Dense1Args d; d.B = n; d.F = F;
@@ -946,7 +933,6 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)(k_conv3x3<128, 32, 256, 8, 1, 1, 1, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 
