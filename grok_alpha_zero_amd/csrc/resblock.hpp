@@ -780,4 +780,132 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_block0(Block0Args a) {
     }
 }
 
+// ---- k_conv_head32: first convolution of a Gomoku head (Gomoku/Build_Model.py: BN, ReLU, Conv3x3 128 -> 32, BN, ReLU) for both
+// heads in one launch (blockIdx.y = head).  Structure of k_conv_heads plus the in-place pre-activation of k_resblock3: the raw
+// trunk output is loaded once per head and transformed in LDS with that head's BN, which removes the two k_affine_relu passes
+// (a 118-MB read and write each) the separate kernels needed.  Output bf16 [M][32] = relu(acc * scale + shift).
+struct Head32Args {
+    const bf16_t* in;                             // [M][128] raw trunk output
+    const bf16_t* wgt[2];                         // fragment order [9][8][2][32][8]
+    const float* s0[2]; const float* t0[2];       // head BN on the input (with ReLU)
+    const float* s1[2]; const float* t1[2];       // BN after the conv folded with its bias (with ReLU)
+    bf16_t* out[2];                               // [M][32]
+    int M, H, W;
+};
+
+__global__ __launch_bounds__(RB3_THREADS, 2) void k_conv_head32(Head32Args a) {
+    constexpr int SLOTS = 16, TM = 2, KS = 8, BN = 32, BSL = BN * SLOTS, RING = 24;
+    constexpr int AROWS = HC_ROWS + 2 * CONV_HALO_MAX + 1, ZROW = AROWS - 1;
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;
+    const int head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int h = a.W + 1, HW = a.H * a.W;
+    const long m0 = (long)blockIdx.x * HC_ROWS;
+    const uint4* in4 = reinterpret_cast<const uint4*>(a.in);
+
+    const int n_aslots = (HC_ROWS + 2 * h) * SLOTS;
+    for (int base = wave * 64; base < n_aslots; base += RB3_THREADS) {
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+        long gr = m0 - h + lr;
+        gr = gr < 0 ? 0 : (gr >= a.M ? (long)a.M - 1 : gr);
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
+    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt[head], 0, 9 * BSL * 16, 0x00020000);
+    const int bvo = (lhi * BN + l31) * 16;
+    auto ldb = [&](int tap, int ks) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, (tap * BSL + ks * 2 * BN) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    uint4 bfr[RING];
+#pragma unroll
+    for (int g = 0; g < RING; ++g) bfr[g] = ldb(g / KS, g % KS);
+    const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;
+    float ps0[8], pt0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps0[j] = a.s0[head][tch0 + j]; pt0[j] = a.t0[head][tch0 + j]; }
+    const float ps1 = a.s1[head][l31], pt1 = a.t1[head][l31];
+
+    int lrow[TM]; unsigned vmask[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wave * TM + tm) * 32 + l31;
+        const long gr = m0 + lrow[tm];
+        unsigned mm = 0;
+        if (gr < a.M) {
+            const int cell = (int)((unsigned)gr % (unsigned)HW), y = cell / a.W, x = cell % a.W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
+            }
+        }
+        vmask[tm] = mm;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.0f;
+    __syncthreads();                                // image landed
+    for (int i = tid; i < n_aslots; i += RB3_THREADS) {        // in-place pre-activation with this head's BN
+        uint4 v = As[i];
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps0[2 * j] + pt0[2 * j], 0.0f);
+            const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps0[2 * j + 1] + pt0[2 * j + 1], 0.0f);
+            w[j] = pack_bf16(lo, hi);
+        }
+        As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t3 = 0; t3 < 3; ++t3) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int tap = t3 * 3 + tt;
+            const int off = (t3 - 1) * a.W + (tt - 1);
+            int abase[TM], axor[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bool ok = (vmask[tm] >> tap) & 1u;
+                const int ar = ok ? lrow[tm] + h + off : ZROW;
+                abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+            }
+            uint4 afr[2][TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                }
+                const bf16x8 bf = *reinterpret_cast<bf16x8*>(&bfr[tt * KS + ks]);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf, acc[tm], 0, 0, 0);
+                const int ntap = tap + 3 < 9 ? tap + 3 : tap;
+                bfr[tt * KS + ks] = ldb(ntap, ks);
+            }
+        }
+    }
+    // C/D layout: col = l31 (channel), row = (r & 3) + 8 (r >> 2) + 4 lhi: 64 contiguous bytes per row and half-wave
+    bf16_t* out = a.out[head];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wave * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const long gr = m0 + row;
+            if (gr < a.M) out[(size_t)gr * 32 + l31] = (bf16_t)(pack_bf16(fmaxf(acc[tm][r] * ps1 + pt1, 0.0f), 0.0f) & 0xFFFFu);
+        }
+}
+
 }  // namespace gaz

@@ -810,8 +810,7 @@ struct GenericEvaluator : Evaluator {
                 const Rb3Plan plan = rb3_plan(M, H, W, n_cus);
                 rb3_launch(s, r, plan, plan.tm == 4 ? 4 : 8);
                 cur = r.xout; fused_blocks++;
-                if (last) hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("p.bn0.scale"), g("p.bn0.shift"), Aa, (long)M * F / 8, F);
-                continue;
+                continue;                           // the heads pre-activate the raw output themselves (k_conv_head32)
             }
             const bf16_t* ain = first ? A0 : Aa;
             const float* sB = last ? (gomoku ? g("p.bn0.scale") : nullptr) : (fuse ? nullptr : g(nb + ".bn1.scale"));
@@ -838,9 +837,18 @@ struct GenericEvaluator : Evaluator {
         }
         if (timing) hipEventRecord(e1, s);
         if (gomoku) {
-            hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("v.bn0.scale"), g("v.bn0.shift"), Va, (long)M * F / 8, F);
-            conv_mfma32(s, Aa, b16["p.c1.w"], g("p.c1.scale"), g("p.c1.shift"), PH, M);
-            conv_mfma32(s, Va, b16["v.c1.w"], g("v.c1.scale"), g("v.c1.shift"), VH, M);
+            if (fuse) {                             // both heads' BN + ReLU + Conv3x3 128 -> 32 + BN + ReLU from the raw trunk output
+                Head32Args hh; memset(&hh, 0, sizeof(hh));
+                hh.in = cur; hh.wgt[0] = b16["p.c1.w"]; hh.wgt[1] = b16["v.c1.w"];
+                hh.s0[0] = g("p.bn0.scale"); hh.t0[0] = g("p.bn0.shift"); hh.s0[1] = g("v.bn0.scale"); hh.t0[1] = g("v.bn0.shift");
+                hh.s1[0] = g("p.c1.scale"); hh.t1[0] = g("p.c1.shift"); hh.s1[1] = g("v.c1.scale"); hh.t1[1] = g("v.c1.shift");
+                hh.out[0] = PH; hh.out[1] = VH; hh.M = M; hh.H = H; hh.W = W;
+                hipLaunchKernelGGL(k_conv_head32, dim3((M + HC_ROWS - 1) / HC_ROWS, 2), dim3(RB3_THREADS), hc_lds_bytes(), s, hh);
+            } else {
+                hipLaunchKernelGGL(k_affine_relu, dim3((unsigned)(((long)M * F / 8 + 255) / 256)), dim3(256), 0, s, cur, g("v.bn0.scale"), g("v.bn0.shift"), Va, (long)M * F / 8, F);
+                conv_mfma32(s, Aa, b16["p.c1.w"], g("p.c1.scale"), g("p.c1.shift"), PH, M);
+                conv_mfma32(s, Va, b16["v.c1.w"], g("v.c1.scale"), g("v.c1.shift"), VH, M);
+            }
             {
                 ConvSmallArgs c; c.in = PH; c.w = g("p.c2.w"); c.bias = g("p.c2.bias"); c.flat = pfeat; c.fs = g("p.bn2.scale"); c.ft = g("p.bn2.shift");
                 c.act = NACT_RELU; c.M = M; c.H = H; c.W = W;
@@ -901,6 +909,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
         *err = "hipMalloc failed"; delete e; return nullptr;
     }
     hipFuncSetAttribute((const void*)(k_block0<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
+    hipFuncSetAttribute((const void*)k_conv_head32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
