@@ -198,7 +198,7 @@ template <class G> struct EngineT : gaz_engine {
             hipMemcpy(h.data(), E.prof, h.size() * 8, hipMemcpyDeviceToHost);
             unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t i = 0; i < h.size(); ++i) t[i % 8] += h[i];
-            const char* nm[7] = {"consume", "select", "expand_pre", "cache_probe", "expand_post(hit)", "terminal backup", "whole launch"};
+            const char* nm[7] = {"consume", "select / descent", "expand_pre", "cache_probe", "expand_post(hit)", "terminal backup", "whole launch"};
             fprintf(stderr, "[tree prof] launches/game %.0f\n", (double)t[7] / E.n_games);
             for (int k = 0; k < 7; ++k) fprintf(stderr, "[tree prof] %-18s %8.0f cycles / game-launch (%.1f %%)\n", nm[k], (double)t[k] / (double)t[7], 100.0 * t[k] / t[6]);
         }

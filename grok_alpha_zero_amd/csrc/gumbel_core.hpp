@@ -92,9 +92,71 @@ template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
 }
 
 // compute_pi(use_softmax=True) for node nd (MCTS_Gumbel.py:126-141 with :113-124, :99-103, :106-110).  Result f32 in S.pri.
+#ifndef GAZ_HOST_EMU
+// sum of v over lanes 0..n-1 in numpy's order for n < 8 (res = 0; res += a[i]), every lane gets the result
+template <class T> GAZ_DEV T seq_sum_lanes(T v, int n) {
+    T res = (T)0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const T vi = shfl(v, i); if (i < n) res = res + vi; }
+    return res;
+}
+template <class T> GAZ_DEV T max_lanes(T v, int n) {               // max over lanes 0..n-1 (n >= 1), starting from lane 0 like the loop it replaces
+    T m = shfl(v, 0);
+#pragma unroll
+    for (int i = 1; i < 7; ++i) { const T vi = shfl(v, i); if (i < n && vi > m) m = vi; }
+    return m;
+}
+template <class T> GAZ_DEV T min_lanes(T v, int n) {
+    T m = shfl(v, 0);
+#pragma unroll
+    for (int i = 1; i < 7; ++i) { const T vi = shfl(v, i); if (i < n && vi < m) m = vi; }
+    return m;
+}
+
+// compute_pi for nodes with fewer than 8 children (every Connect4 node): child i lives in lane i and the fourteen
+// LDS write -> fence -> read phases of the general version become register shuffles; same operations in the same order.
+template <class G> GAZ_DEV void compute_pi_small(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S,
+                                                 uint32_t& N_b_out, uint64_t& sumv_out) {
+    const int i = lane_id();
+    const bool on = i < n;
+    const uint32_t Ni = on ? nd.N()[i] : 0u;
+    const float Wi = on ? nd.W()[i] : 0.0f, Li = on ? nd.P()[i] : 0.0f, RAWi = on ? RAW[i] : 0.0f;
+    uint32_t nb = 0; uint64_t sumv = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { const uint32_t v = shfl(Ni, k); if (k < n) { if (v > nb) nb = v; sumv += v; } }
+    // softmax #1 (float64)
+    double x = (double)Li;
+    double mx = max_lanes(x, n);
+    double e = det::dexp(x + (-mx));
+    double ssum = seq_sum_lanes(e, n);
+    const float pri = (float)(e / ssum);
+    const float mean = Ni > 0 ? (float)((double)Wi / (double)Ni) : -1.0f;
+    const float q = (mean - (-1.0f)) / 2.0f;
+    const float sum_probs = seq_sum_lanes(Ni > 0 ? pri : 0.0f, n);
+    const float weighted_q = seq_sum_lanes(Ni > 0 ? (pri * q) / sum_probs : 0.0f, n);
+    const double wq = (double)weighted_q * (double)sumv;
+    const float vmix = (float)(((double)RAWi + wq) / (double)(sumv + 1));
+    const float cq = Ni > 0 ? q : vmix;                                                                // completed_q
+    const float mn = min_lanes(cq, n), mxq = max_lanes(cq, n);
+    const float den = (mxq - mn) > F32_EPS ? (mxq - mn) : F32_EPS;
+    const double sg = (E.c_visit + (double)nb) * E.c_scale;
+    const float r = (cq - mn) / den;
+    x = (double)Li + sg * (double)r;
+    mx = max_lanes(x, n);
+    e = det::dexp(x + (-mx));
+    ssum = seq_sum_lanes(e, n);
+    if (on) S.pri[i] = (float)(e / ssum);
+    wave_sync();
+    N_b_out = nb; sumv_out = sumv;
+}
+#endif
+
 // nd may be the LDS copy of the record (g_stage_node); RAW is passed separately because it is not contiguous with the header.
 template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S, uint32_t& N_b_out,
                                            uint64_t& sumv_out) {
+#ifndef GAZ_HOST_EMU
+    if (n < 8) { compute_pi_small<G>(E, nd, RAW, n, S, N_b_out, sumv_out); return; }
+#endif
     const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P();
     uint32_t nb = 0; uint64_t sumv = 0;                                                              // uniform
     if (n <= 8) {
@@ -250,11 +312,13 @@ template <class G> GAZ_DEV void g_write_children(const DevParams<G>& E, int g, c
 }
 
 // _expand of child `index` of `node`; path[0..depth) leads to node.  true = evaluation pending
+// `staged`: the descent left this node's header + child blocks in S.node (saves two dependent round trips)
 template <class G> GAZ_DEV bool g_expand_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, Scratch<G>& S,
-                                             int node, int index, int depth) {
+                                             int node, int index, int depth, bool staged = false) {
     NodeRef<G> pn = node_at(E, g, 0, node);
-    const NodeHdr ph = *pn.hdr();
-    const int action = uni((int)pn.act()[index]);
+    const NodeRef<G> ps = staged ? NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)} : pn;
+    const NodeHdr ph = *ps.hdr();
+    const int action = uni((int)ps.act()[index]);
     const int mover = -(int)uni((int)ph.player);
     copy_board<G>(S.board, pn.board());
     wave_sync();
@@ -352,6 +416,8 @@ template <class G> GAZ_DEV void g_move_end(const DevParams<G>& E, int g, GameSta
 template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts) {
     using RL = RecLayout<G>;
 
+    const long long tp0 = GAZ_PROF_NOW();
+    if (E.prof && lane_id() == 0) E.prof[(size_t)g * 8 + 7] += 1;
     if (uni(gs.pend_kind) == PEND_ROOT) {
         g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S, E.nn_policy + (size_t)g * G::A);
         if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo = 0; gs.n_evals += 1; }
@@ -365,6 +431,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
         wave_sync();
     }
 
+    GAZ_PROF(0, tp0);
     int tree_only = 0;
     for (int guard = 0; guard < 100000; ++guard) {
         const int phase = uni(gs.phase);
@@ -451,6 +518,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             // one simulation below root child `id`
             int node = ts.root, depth = 0, slot = id;
             bool done = false, pending = false, staged = false;
+            const long long td0 = GAZ_PROF_NOW();
             for (;;) {
                 // below the root the record of `node` is already in LDS (staged for its deterministic_selection)
                 const int c = staged ? uni(NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)}.child()[slot]) : uni(node_at(E, g, 0, node).child()[slot]);
@@ -458,7 +526,9 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 if (c == CHILD_NONE) {                                         // expand (node, slot)
                     if (lane_id() == 0) gu.pend_counts = 1;
                     wave_sync();
-                    pending = g_expand_pre<G>(E, g, gs, ts, S, node, slot, depth);
+                    const long long te0 = GAZ_PROF_NOW();
+                    pending = g_expand_pre<G>(E, g, gs, ts, S, node, slot, depth, staged);
+                    GAZ_PROF(2, te0);
                     done = !pending;
                     break;
                 }
@@ -473,11 +543,16 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 NodeRef<G> cn = g_stage_node<G>(E, g, node, S); staged = true;
                 slot = g_det_select<G>(E, cn, S.raw, uni((int)cn.hdr()->n_actions), S);
             }
+            GAZ_PROF(1, td0);                                              // descent incl. its expand_pre (slot 2 is counted twice)
             if (pending) {
+                const long long tc0 = GAZ_PROF_NOW();
                 const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
+                GAZ_PROF(3, tc0);
                 if (!hit) return;
+                const long long tx0 = GAZ_PROF_NOW();
                 g_expand_post<G>(E, g, gs, ts, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                  reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: the simulation completes in this launch
+                GAZ_PROF(4, tx0);
                 if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                 wave_sync();
                 done = true;
@@ -540,11 +615,13 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
     GameState<G>* gsG = &E.games[g];
     GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
     TreeState* tsG = &E.trees[(size_t)g * 2];
+    const long long tw0 = GAZ_PROF_NOW();
     copy_state_words(&L.gs, gsG); copy_state_words(&L.gu, guG); copy_state_words(&L.ts, tsG);
     wave_sync();
     g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
     wave_sync();
     copy_state_words(gsG, &L.gs); copy_state_words(guG, &L.gu); copy_state_words(tsG, &L.ts);
+    GAZ_PROF(6, tw0);
 }
 
 }  // namespace gaz
