@@ -116,7 +116,7 @@ template <class T> GAZ_DEV T min_lanes(T v, int n) {
 // compute_pi for nodes with fewer than 8 children (every Connect4 node): child i lives in lane i and the fourteen
 // LDS write -> fence -> read phases of the general version become register shuffles; same operations in the same order.
 template <class G> GAZ_DEV void compute_pi_small(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S,
-                                                 uint32_t& N_b_out, uint64_t& sumv_out) {
+                                                 uint32_t& N_b_out, uint64_t& sumv_out, bool stable) {
     const int i = lane_id();
     const bool on = i < n;
     const uint32_t Ni = on ? nd.N()[i] : 0u;
@@ -124,12 +124,18 @@ template <class G> GAZ_DEV void compute_pi_small(const DevParams<G>& E, const No
     uint32_t nb = 0; uint64_t sumv = 0;
 #pragma unroll
     for (int k = 0; k < 7; ++k) { const uint32_t v = shfl(Ni, k); if (k < n) { if (v > nb) nb = v; sumv += v; } }
-    // softmax #1 (float64)
-    double x = (double)Li;
-    double mx = max_lanes(x, n);
-    double e = det::dexp(x + (-mx));
-    double ssum = seq_sum_lanes(e, n);
-    const float pri = (float)(e / ssum);
+    double x, mx, e, ssum;
+    float pri;
+    if (stable) {                                           // stablemax(float32 logits)
+        const float sf = Li >= 0.0f ? Li + 1.0f : 1.0f / ((1.0f - Li) + F32_EPS);
+        pri = sf / seq_sum_lanes(sf, n);
+    } else {                                                // softmax #1 (float64)
+        x = (double)Li;
+        mx = max_lanes(x, n);
+        e = det::dexp(x + (-mx));
+        ssum = seq_sum_lanes(e, n);
+        pri = (float)(e / ssum);
+    }
     const float mean = Ni > 0 ? (float)((double)Wi / (double)Ni) : -1.0f;
     const float q = (mean - (-1.0f)) / 2.0f;
     const float sum_probs = seq_sum_lanes(Ni > 0 ? pri : 0.0f, n);
@@ -142,20 +148,29 @@ template <class G> GAZ_DEV void compute_pi_small(const DevParams<G>& E, const No
     const double sg = (E.c_visit + (double)nb) * E.c_scale;
     const float r = (cq - mn) / den;
     x = (double)Li + sg * (double)r;
-    mx = max_lanes(x, n);
-    e = det::dexp(x + (-mx));
-    ssum = seq_sum_lanes(e, n);
-    if (on) S.pri[i] = (float)(e / ssum);
+    if (stable) {                                           // stablemax in float64, left in S.gam
+        const double sd = x >= 0.0 ? x + 1.0 : 1.0 / ((1.0 - x) + (double)F32_EPS);
+        const double tot = seq_sum_lanes(sd, n);
+        if (on) S.gam[i] = sd / tot;
+    } else {
+        mx = max_lanes(x, n);
+        e = det::dexp(x + (-mx));
+        ssum = seq_sum_lanes(e, n);
+        if (on) S.pri[i] = (float)(e / ssum);
+    }
     wave_sync();
     N_b_out = nb; sumv_out = sumv;
 }
 #endif
 
 // nd may be the LDS copy of the record (g_stage_node); RAW is passed separately because it is not contiguous with the header.
+// stable = true: compute_pi(use_softmax=False) as numpy 2 evaluates it without Numba (MCTS_Gumbel.py:144-148): probs =
+// stablemax(float32 logits); sigma is float64 ((c_visit + N_b) is a NumPy float64 scalar), so logits + sigma and the second
+// stablemax are float64 and the result is NOT cast to float32: it is left in S.gam (S.pri is not written).
 template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S, uint32_t& N_b_out,
-                                           uint64_t& sumv_out) {
+                                           uint64_t& sumv_out, bool stable = false) {
 #ifndef GAZ_HOST_EMU
-    if (n < 8) { compute_pi_small<G>(E, nd, RAW, n, S, N_b_out, sumv_out); return; }
+    if (n < 8) { compute_pi_small<G>(E, nd, RAW, n, S, N_b_out, sumv_out, stable); return; }
 #endif
     const uint32_t* N = nd.N(); const float* W = nd.W(); const float* L = nd.P();
     uint32_t nb = 0; uint64_t sumv = 0;                                                              // uniform
@@ -168,9 +183,18 @@ template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<
     } else {
         for (int i = 0; i < n; ++i) { uint32_t v = N[i]; if (v > nb) nb = v; sumv += v; }
     }
-    for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)L[i];
-    wave_sync();
-    softmax_inplace<G>(S, n);
+    if (stable) {                                           // stablemax(float32 logits), np.sum in float32
+        for (int i = lane_id(); i < n; i += WAVE) { const float l = L[i]; S.spri[i] = l >= 0.0f ? l + 1.0f : 1.0f / ((1.0f - l) + F32_EPS); }
+        wave_sync();
+        const float ssum = det::np_pairwise_sum<float>(S.spri, n);
+        wave_sync();
+        for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)(S.spri[i] / ssum);
+        wave_sync();
+    } else {
+        for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)L[i];
+        wave_sync();
+        softmax_inplace<G>(S, n);
+    }
     // probs (f32) in S.pri; q in S.aux
     for (int i = lane_id(); i < n; i += WAVE) {
         S.pri[i] = (float)S.gam[i];
@@ -207,19 +231,29 @@ template <class G> GAZ_DEV void compute_pi(const DevParams<G>& E, const NodeRef<
     wave_sync();
     for (int i = lane_id(); i < n; i += WAVE) { const float r = (S.spri[i] - mn) / den; S.gam[i] = (double)L[i] + sg * (double)r; }
     wave_sync();
-    softmax_inplace<G>(S, n);
-    for (int i = lane_id(); i < n; i += WAVE) S.pri[i] = (float)S.gam[i];
-    wave_sync();
+    if (stable) {                                           // stablemax in float64, result stays in S.gam
+        for (int i = lane_id(); i < n; i += WAVE) { const double x = S.gam[i]; S.gam[i] = x >= 0.0 ? x + 1.0 : 1.0 / ((1.0 - x) + (double)F32_EPS); }
+        wave_sync();
+        const double ssum = det::np_pairwise_sum<double>(S.gam, n);
+        wave_sync();
+        for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = S.gam[i] / ssum;
+        wave_sync();
+    } else {
+        softmax_inplace<G>(S, n);
+        for (int i = lane_id(); i < n; i += WAVE) S.pri[i] = (float)S.gam[i];
+        wave_sync();
+    }
     N_b_out = nb; sumv_out = sumv;
 }
 
 // deterministic_selection: argmax(pi - visits / (1 + sum(visits))) in float64, first maximum (MCTS_Gumbel.py:243)
 template <class G> GAZ_DEV int g_det_select(const DevParams<G>& E, const NodeRef<G>& nd, const float* RAW, int n, Scratch<G>& S) {
     uint32_t nb; uint64_t sumv;
-    compute_pi<G>(E, nd, RAW, n, S, nb, sumv);
+    const bool stable = E.g_stablemax != 0;
+    compute_pi<G>(E, nd, RAW, n, S, nb, sumv, stable);
     double best = 0.0; int bi = 0x7fffffff;
     for (int i = lane_id(); i < n; i += WAVE) {
-        double sc = (double)S.pri[i] - (double)nd.N()[i] / (double)(1 + sumv);
+        double sc = (stable ? S.gam[i] : (double)S.pri[i]) - (double)nd.N()[i] / (double)(1 + sumv);
         if (bi == 0x7fffffff || sc > best) { best = sc; bi = i; }
     }
     wave_argmax(best, bi);

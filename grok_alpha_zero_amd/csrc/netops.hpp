@@ -193,7 +193,14 @@ __global__ __launch_bounds__(64) void k_softmax_rows(const float* in, float* out
     if (b >= B) return;
     float v[4]; float mx = -3.0e38f;
     for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; v[j] = i < A ? in[(size_t)b * A + i] : -3.0e38f; mx = fmaxf(mx, v[j]); }
-    if (logits) { for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; if (i < A) out[(size_t)b * A + i] = v[j]; } return; }
+    if (logits == 1) { for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; if (i < A) out[(size_t)b * A + i] = v[j]; } return; }
+    if (logits == 2) {                                              // Stablemax layer (Net/Stablemax.py:8-12)
+        float sx[4], ssum = 0.0f;
+        for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; sx[j] = i < A ? (v[j] >= 0.0f ? v[j] + 1.0f : 1.0f / (1.0f - v[j])) : 0.0f; ssum += sx[j]; }
+        for (int m = 32; m >= 1; m >>= 1) ssum += __shfl_xor(ssum, m, 64);
+        for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; if (i < A) out[(size_t)b * A + i] = sx[j] / ssum; }
+        return;
+    }
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
     float e[4], sum = 0.0f;
     for (int j = 0; j < 4; ++j) { const int i = l + 64 * j; e[j] = i < A ? expf(v[j] - mx) : 0.0f; sum += e[j]; }

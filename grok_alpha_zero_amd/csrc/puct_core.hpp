@@ -37,6 +37,7 @@ template <class G> struct DevParams {
     double c_init, c_base, alpha, eps;
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
     int32_t gumbel_m, node_bytes, compact;
+    int32_t g_stablemax;       // Gumbel: activation_fn = "stablemax" in deterministic_selection (Self_Play.py:69)
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
     int32_t tau_mode;          // -1: Self_Play's exploration schedule; 0 / 1: tau fixed by the caller (MCTS.update_hyperparams)
     int32_t n_opening, opening_actions[8];   // train_config["opening_actions"] (Self_Play.py:130-140)

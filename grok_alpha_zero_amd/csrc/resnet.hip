@@ -434,8 +434,13 @@ __global__ __launch_bounds__(128) void k_tail(TailArgs a) {
     const int b = b0 + p;
     if (head == 0) {
         for (int o = q; o < nout; o += 8) {
-            if (a.logits) a.policy[(size_t)b * a.A + o] = lg[p][o];
-            else {
+            if (a.logits == 1) a.policy[(size_t)b * a.A + o] = lg[p][o];
+            else if (a.logits == 2) {               // Stablemax layer (Net/Stablemax.py:8-12): s(x) = x + 1 | 1 / (1 - x), normalised
+                float sum = 0.f;
+                for (int k = 0; k < nout; ++k) { const float x = lg[p][k]; sum += x >= 0.0f ? x + 1.0f : 1.0f / (1.0f - x); }
+                const float x = lg[p][o];
+                a.policy[(size_t)b * a.A + o] = (x >= 0.0f ? x + 1.0f : 1.0f / (1.0f - x)) / sum;
+            } else {
                 float mx = lg[p][0];
                 for (int k = 1; k < nout; ++k) mx = fmaxf(mx, lg[p][k]);
                 float sum = 0.f;

@@ -7,7 +7,7 @@ simulation with a batch of one, exactly where the reference calls it.  `session=
 
 For throughput use `SelfPlayEngine` / `run_self_play` (thousands of games per launch); these classes exist so code written
 against the reference (`<Game>/play.py`, `Game_Tester.py:480-513`) keeps working.
-Not supported: `time_limit` (iteration limits only), `fast_find_win=True`, `use_njit` (ignored).
+Not supported: `time_limit` (iteration limits only), `fast_find_win=True`; `use_njit` is ignored.
 """
 import os
 from warnings import warn
@@ -121,13 +121,15 @@ class MCTS(_EngineSearch):
 class MCTS_Gumbel(_EngineSearch):
     def __init__(self, game, session, use_gumbel_noise=False, use_njit=None, m=16, c_visit=50.0, c_scale=0.1,
                  activation_fn="softmax", fast_find_win=False, *, seed=None, hash_salt=0, max_actions=None, lib_path=None):
-        if fast_find_win or activation_fn != "softmax":
-            raise NotImplementedError("fast_find_win / stablemax are not supported")
+        if fast_find_win:
+            raise NotImplementedError("fast_find_win=True is not supported")
+        if activation_fn not in ("softmax", "stablemax"):
+            raise ValueError("activation_fn must be 'softmax' or 'stablemax'")
         if not use_gumbel_noise:
             warn("the engine always adds Gumbel noise at the root (Self_Play.py:64 uses use_gumbel_noise=True)")
         self.m, self.c_visit, self.c_scale = m, c_visit, c_scale
         self._attach(game, session, seed, lib_path, max_actions=max_actions or int(np.prod(game.board.shape)), hash_salt=hash_salt,
-                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale)
+                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale, gumbel_stablemax=activation_fn == "stablemax")
 
     def update_hyperparams(self, *args, **kwargs):
         for k in ("m", "c_visit", "c_scale"):

@@ -234,6 +234,8 @@ class GomokuNet(nn.Module):
         p = self.p_d2(F.relu(self.p_bn3(self.p_d1(F.relu(self.p_bn2(p))))))
         if self.policy_head == "softmax":
             p = torch.softmax(p.double(), -1).float()
+        elif self.policy_head == "stablemax":
+            p = stablemax(p)
         v = self.v_c2(F.relu(self.v_bn1(self.v_c1(F.relu(self.v_bn0(x)))))).reshape(B, -1)
         v = F.relu(self.v_bn3(self.v_d1(F.relu(self.v_bn2(v)))))
         v = torch.tanh(self.v_d3(F.relu(self.v_bn4(self.v_d2(v)))))
@@ -305,6 +307,8 @@ class TicTacToeNet(nn.Module):
         p = self.p_d3(self.p_d2(F.relu(self.p_d1(p))))
         if self.policy_head == "softmax":
             p = torch.softmax(p, -1)
+        elif self.policy_head == "stablemax":
+            p = stablemax(p)
         v = self.v_bn(self.v_conv(x)).reshape(B, -1)
         v = torch.tanh(self.v_d3(F.relu(self.v_d2(self.v_d1(v)))))
         return p, v

@@ -160,7 +160,9 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                          train_config.get("c_puct_init", 0.0), train_config.get("dirichlet_alpha", 0.0), seed,
                          search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=train_config.get("m", 0),
                          c_visit=train_config.get("c_visit", 50.0), c_scale=train_config.get("c_scale", 1.0),
-                         policy_is_logits=gumbel,
+                         # policy head: raw logits for Gumbel, else Stablemax or softmax (Build_Model.py:54-60)
+                         policy_is_logits=1 if gumbel else (2 if build_config.get("use_stablemax") else 0),
+                         gumbel_stablemax=bool(gumbel and build_config.get("use_stablemax")),
                          opening_actions=[(game_class.action_to_index(a) if hasattr(game_class, "action_to_index") else int(a), w)
                                           for a, w in train_config.get("opening_actions", []) or []],
                          create_new_root=train_config.get("create_new_root", False), slot_offset=slot_offset, device=device,

@@ -60,7 +60,8 @@ typedef struct {
     int32_t device;               /* HIP device ordinal */
     /* ResNet (evaluator == GAZ_EVAL_RESNET): trunk of `net_blocks` pre-activation blocks x `net_filters` */
     int32_t net_blocks, net_filters;
-    int32_t policy_is_logits;     /* 1: evaluator emits raw logits (Gumbel), 0: probabilities (softmax) */
+    int32_t policy_is_logits;     /* policy head: 0 = softmax (float64, Build_Model.py:60), 1 = raw logits (Gumbel),
+                                     2 = stablemax (Net/Stablemax.py:8-12, build_config["use_stablemax"]) */
     int32_t gumbel_m;             /* train_config["m"]: actions sampled in the first stage of sequential halving */
     double c_visit, c_scale;      /* train_config["c_visit"], ["c_scale"] (MCTS_Gumbel.py:160-161) */
     int32_t compact_trees;        /* re-root compaction of the tree arena: 0 = auto (on for Gomoku), 1 = on, -1 = off */
@@ -73,6 +74,8 @@ typedef struct {
     int32_t eval_cache_log2;      /* on-device evaluation cache with 2^n entries, keyed by the encoded leaf state (replaces
                                      Session_Cache.Cache_Wrapper, Session_Cache.py:4-26 / Self_Play.py:234-236); 0 = off.
                                      A hit returns the bits the evaluator produced for the same input: results do not change */
+    int32_t gumbel_stablemax;     /* 1: MCTS_Gumbel(activation_fn="stablemax") — build_config["use_stablemax"] (Self_Play.py:69):
+                                     stablemax instead of softmax inside deterministic_selection (MCTS_Gumbel.py:144-148) */
 } gaz_engine_config;
 
 typedef struct {

@@ -122,6 +122,43 @@ static void g_compute_pi(const float* raw_values, const float* q, const float* l
     for (int i = 0; i < n; ++i) pi[i] = (float)p64[i];
 }
 
+/* stablemax (MCTS_Gumbel.py:77-80; Net/Stablemax.py without the eps): s(x) = x + 1 (x >= 0) else 1 / (1 - x + eps32), normalised */
+static void g_stablemax_f32(const float* x, int n, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = x[i] >= 0.0f ? x[i] + 1.0f : 1.0f / ((1.0f - x[i]) + F32_EPS);
+    float s = gaz_np_sum_f32(out, n);
+    for (int i = 0; i < n; ++i) out[i] = out[i] / s;
+}
+static void g_stablemax_f64(const double* x, int n, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = x[i] >= 0.0 ? x[i] + 1.0 : 1.0 / ((1.0 - x[i]) + (double)F32_EPS);
+    double s = gaz_np_sum_f64(out, n);
+    for (int i = 0; i < n; ++i) out[i] = out[i] / s;
+}
+
+/* compute_pi(use_softmax=False) (MCTS_Gumbel.py:144-148) as numpy 2 evaluates it without Numba: probs = stablemax(float32 logits);
+ * sigma(...) is float64 because (c_visit + N_b) is a NumPy float64 scalar, so logits + sigma and the second stablemax are float64
+ * and the result is NOT cast back to float32 */
+static void g_compute_pi_stable(const float* raw_values, const float* q, const float* logits, const uint32_t* visits, int n,
+                                uint32_t N_b, double c_visit, double c_scale, double* pi) {
+    double l64[MAXA]; float probs[MAXA], tmp[MAXA], cq[MAXA];
+    g_stablemax_f32(logits, n, probs);
+    uint64_t sum_visits = 0; for (int i = 0; i < n; ++i) sum_visits += visits[i];
+    for (int i = 0; i < n; ++i) tmp[i] = visits[i] > 0 ? probs[i] : 0.0f;
+    float sum_probs = gaz_np_sum_f32(tmp, n);
+    for (int i = 0; i < n; ++i) tmp[i] = visits[i] > 0 ? (probs[i] * q[i]) / sum_probs : 0.0f;
+    float weighted_q = gaz_np_sum_f32(tmp, n);
+    double wq = (double)weighted_q * (double)sum_visits;
+    for (int i = 0; i < n; ++i) {
+        float vmix = (float)(((double)raw_values[i] + wq) / (double)(sum_visits + 1));
+        cq[i] = visits[i] > 0 ? q[i] : vmix;
+    }
+    float mn = cq[0], mx = cq[0];
+    for (int i = 1; i < n; ++i) { if (cq[i] < mn) mn = cq[i]; if (cq[i] > mx) mx = cq[i]; }
+    float den = (mx - mn) > F32_EPS ? (mx - mn) : F32_EPS;
+    double sg = (c_visit + (double)N_b) * c_scale;
+    for (int i = 0; i < n; ++i) { float r = (cq[i] - mn) / den; l64[i] = (double)logits[i] + sg * (double)r; }
+    g_stablemax_f64(l64, n, pi);
+}
+
 static void g_mean_q(const gnode* x, float* q) {   /* mean_values + q_transform (MCTS_Gumbel.py:238-240, 91-97) */
     for (int i = 0; i < x->n; ++i) {
         float mean = x->visits[i] > 0 ? (float)((double)x->values[i] / (double)x->visits[i]) : -1.0f;
@@ -134,10 +171,12 @@ static int g_det_select(ggumbel* t, const gnode* x) {
     float q[MAXA], pi[MAXA]; uint32_t nb = 0; uint64_t sv = 0;
     g_mean_q(x, q);
     for (int i = 0; i < x->n; ++i) { if (x->visits[i] > nb) nb = x->visits[i]; sv += x->visits[i]; }
-    g_compute_pi(x->raw_values, q, x->logits, x->visits, x->n, nb, t->c_visit, t->c_scale, pi);
+    double pi64[MAXA];
+    if (t->use_softmax) { g_compute_pi(x->raw_values, q, x->logits, x->visits, x->n, nb, t->c_visit, t->c_scale, pi); for (int i = 0; i < x->n; ++i) pi64[i] = (double)pi[i]; }
+    else g_compute_pi_stable(x->raw_values, q, x->logits, x->visits, x->n, nb, t->c_visit, t->c_scale, pi64);
     int best = 0; double bs = 0;
     for (int i = 0; i < x->n; ++i) {
-        double s = (double)pi[i] - (double)x->visits[i] / (double)(1 + sv);
+        double s = pi64[i] - (double)x->visits[i] / (double)(1 + sv);
         if (i == 0 || s > bs) { bs = s; best = i; }
     }
     return best;
@@ -301,12 +340,12 @@ int gaz_selfplay_game_gumbel(const gaz_sp_config* cfg, int m, double c_visit, do
     int HW = g.H * g.W, SZ = HW * g.C, A = g.A;
     int8_t board[225]; int history[256]; int n_history = 0, next_player = -1;
     memset(board, 0, sizeof(board));
-    g_libm = use_libm;
+    g_libm = use_libm & 1;                           /* bit 1 of use_libm: activation_fn = "stablemax" (Self_Play.py:69) */
     gaz_event ev; ev.key[0] = (uint32_t)seed; ev.key[1] = (uint32_t)(seed >> 32); ev.slot = slot; ev.game_seq = game_seq;
     ev.event = 0; ev.tree = 0; ev.purpose = 0;
     ggumbel t; memset(&t, 0, sizeof(t));
     t.g = g; t.game_board = board; t.game_history = history; t.game_n_history = &n_history; t.game_next_player = &next_player;
-    t.eval = eval; t.eval_ctx = ctx; t.m = m; t.c_visit = c_visit; t.c_scale = c_scale; t.use_gumbel_noise = 1; t.use_softmax = 1;
+    t.eval = eval; t.eval_ctx = ctx; t.m = m; t.c_visit = c_visit; t.c_scale = c_scale; t.use_gumbel_noise = 1; t.use_softmax = (use_libm & 2) ? 0 : 1;
     t.ev = &ev;
     int winner = GAZ_RUNNING, T = 0, actions_count = 0; gaz_move_row rows[225]; int n_rows;
     g_create_root(&t);

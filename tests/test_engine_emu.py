@@ -121,7 +121,8 @@ def play_gumbel_fixture(fx, lib_path):
     from grok_alpha_zero_amd.engine import SelfPlayEngine, SEARCH_GUMBEL
     eng = SelfPlayEngine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), 0, 0, 0.0, 0.0, int(fx["seed"]),
                          slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8, search=SEARCH_GUMBEL,
-                         gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]), lib_path=lib_path)
+                         gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]),
+                         gumbel_stablemax=bool(int(fx["stablemax"])) if "stablemax" in fx else False, lib_path=lib_path)
     recs = []
     for _ in range(20000):
         eng.run_waves(64)

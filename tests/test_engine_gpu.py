@@ -125,7 +125,8 @@ def test_hip_gumbel_engine_matches_reference_fixture(name):
     seq = int(fx["game_seq"])
     eng = _engine(str(fx["game"]), 1, int(fx["run_iterations"]), int(fx["max_actions"]), 0, 0, 0.0, 0.0, int(fx["seed"]),
                   slot_offset=int(fx["slot"]), hash_salt=int(fx["salt"]), ring_capacity=8, search=SEARCH_GUMBEL,
-                  gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]))
+                  gumbel_m=int(fx["m"]), c_visit=float(fx["c_visit"]), c_scale=float(fx["c_scale"]),
+                  gumbel_stablemax=bool(int(fx["stablemax"])) if "stablemax" in fx else False)
     recs = _play_until(eng, lambda rs: any(r["game_seq"] == seq for r in rs))
     r = [x for x in recs if x["game_seq"] == seq][0]
     assert r["T"] == len(fx["actions"])

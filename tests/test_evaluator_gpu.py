@@ -175,3 +175,25 @@ def test_two_half_pipeline_gives_identical_games(tmp_path):
         outs.append(r.stdout.strip().splitlines()[-1])
     assert int(outs[0].split()[0]) > 200                   # games did finish
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("game,blocks,n", [("Connect4", 3, 200), ("TicTacToe", 2, 64), ("Gomoku", 2, 64)])
+def test_stablemax_policy_head_matches_torch(game, blocks, n):
+    """policy_is_logits = 2: the Stablemax layer (Net/Stablemax.py:8-12, build_config["use_stablemax"]) as the policy epilogue."""
+    import torch
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    net = NETS[game](blocks, seed=4, policy_head="stablemax").eval()
+    H, W, Cc = net.H, net.W, net.C
+    eng = SelfPlayEngine(game, max(n, 64), 10, H * W, 0, 0, 1.0, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks,
+                         net_filters=64 if game == "TicTacToe" else 128, ring_capacity=0, policy_is_logits=2)
+    eng.load_weights(net.export_engine_weights())
+    rng = np.random.default_rng(5)
+    x = rng.integers(-1, 2, size=(n, H, W, Cc)).astype(np.int8)
+    pol, val, _ = eng.evaluate(x)
+    with torch.no_grad():
+        p_ref, v_ref = net(torch.from_numpy(x))
+    dp = np.abs(pol - p_ref.numpy())
+    assert np.allclose(pol.sum(1), 1.0, atol=1e-5) and (pol > 0).all()
+    assert dp.max() <= 3e-2 and dp.mean() <= 3e-3, (dp.max(), dp.mean())
+    eng.close()

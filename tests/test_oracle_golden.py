@@ -54,7 +54,8 @@ def test_gumbel_selfplay_matches_reference(oracle, name, use_libm):
     fx = np.load(os.path.join(GOLDEN, name + ".npz"))
     r = oracle.selfplay_game_gumbel(str(fx["game"]), int(fx["run_iterations"]), int(fx["max_actions"]), int(fx["m"]),
                                     float(fx["c_visit"]), float(fx["c_scale"]), int(fx["seed"]), int(fx["slot"]),
-                                    int(fx["game_seq"]), hash_salt=int(fx["salt"]), use_libm=use_libm)
+                                    int(fx["game_seq"]), hash_salt=int(fx["salt"]), use_libm=use_libm,
+                                    stablemax=bool(int(fx["stablemax"])) if "stablemax" in fx else False)
     assert r["T"] == len(fx["actions"]) and r["total_evals"] == int(fx["evaluator_calls"])
     for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "states", "policies"):
         np.testing.assert_array_equal(r[k], fx[k], err_msg=k)
@@ -62,7 +63,7 @@ def test_gumbel_selfplay_matches_reference(oracle, name, use_libm):
 
 
 def test_gumbel_fixture_inventory():
-    assert {"ttt_gumbel_a", "c4_gumbel_a", "gmk_gumbel_a"} <= set(GUMBEL_CASES)
+    assert {"ttt_gumbel_a", "c4_gumbel_a", "gmk_gumbel_a", "c4_gumbel_stable_a", "ttt_gumbel_stable_a", "gmk_gumbel_stable_a"} <= set(GUMBEL_CASES)
 
 
 OPENING_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_open*.npz")))

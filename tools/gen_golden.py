@@ -41,11 +41,13 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
                     "use_njit": False, "c_puct_init": c_puct_init, "dirichlet_alpha": alpha,
                     "max_actions": max_actions, "num_explore_actions_first": explore_first,
                     "num_explore_actions_second": explore_second}
+    build_config = {}
     if gumbel is not None:
         train_config.update(use_gumbel=True, m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2])
+        if len(gumbel) > 3 and gumbel[3]:
+            build_config["use_stablemax"] = True           # MCTS_Gumbel(activation_fn="stablemax") (Self_Play.py:69)
     if opening is not None:
         train_config["opening_actions"] = opening
-    build_config = {}
     folder = f"/fake/{game}_{iteration_limit}_{seed}_{slot}_{game_seq}/1"
     ref_shim._FakeH5File.STORE.pop(folder + "/Self_Play_Data.h5", None)
     f = ref_shim._FakeH5File(folder + "/Self_Play_Data.h5")
@@ -83,7 +85,8 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
     if opening is not None:
         out.update(opening_idx=np.array([action_to_index(game, a) for a, _ in opening], np.int32), opening_w=np.array([w for _, w in opening]))
     if gumbel is not None:
-        out.update(m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2], run_iterations=iteration_limit)
+        out.update(m=gumbel[0], c_visit=gumbel[1], c_scale=gumbel[2], run_iterations=iteration_limit,
+                   stablemax=int(len(gumbel) > 3 and bool(gumbel[3])))
     for k in range(n_aug):
         out[f"aug_boards_{k}"] = d[f"boards_{k}"].data
         out[f"aug_policies_{k}"] = d[f"policies_{k}"].data
@@ -136,6 +139,11 @@ GUMBEL_CASES = [
     ("c4_gumbel_b", "Connect4", 32, 42, 7, 50.0, 1.0, 77, 9, 3, 5),
     ("c4_gumbel_c", "Connect4", 64, 42, 4, 50.0, 1.0, 5, 2, 0, 3),
     ("gmk_gumbel_a", "Gomoku", 48, 10, 16, 50.0, 1.0, 1234, 0, 0, 5),
+    # activation_fn = "stablemax" (build_config["use_stablemax"]); the trailing True selects it
+    ("c4_gumbel_stable_a", "Connect4", 32, 42, 7, 50.0, 1.0, 4321, 1, 0, 13, True),
+    ("c4_gumbel_stable_b", "Connect4", 48, 42, 4, 50.0, 0.5, 8, 6, 2, 2, True),
+    ("ttt_gumbel_stable_a", "TicTacToe", 16, 9, 4, 50.0, 2.0, 99, 2, 1, 7, True),
+    ("gmk_gumbel_stable_a", "Gomoku", 40, 8, 16, 50.0, 1.0, 17, 3, 0, 9, True),
 ]
 
 
@@ -162,10 +170,10 @@ def main():
         fx = ref_single_tree_puct(*cfg)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
         print(name, "T =", len(fx["actions"]), "evals", fx["evaluator_calls"], flush=True)
-    for name, game, it, max_actions, m, c_visit, c_scale, seed, slot, seq, salt in GUMBEL_CASES:
+    for name, game, it, max_actions, m, c_visit, c_scale, seed, slot, seq, salt, *rest in GUMBEL_CASES:
         if only and name not in only:
             continue
-        fx = ref_selfplay_puct(game, it, max_actions, 0, 0, 0.0, 0.0, seed, slot, seq, salt, gumbel=(m, c_visit, c_scale))
+        fx = ref_selfplay_puct(game, it, max_actions, 0, 0, 0.0, 0.0, seed, slot, seq, salt, gumbel=(m, c_visit, c_scale, bool(rest and rest[0])))
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
         print(name, "T =", len(fx["actions"]), "stats", fx["game_stats"], "evals", fx["evaluator_calls"], flush=True)
     for name, *cfg in PUCT_CASES:
