@@ -93,23 +93,32 @@ template <class G> GAZ_DEV void softmax_inplace(Scratch<G>& S, int n) {
 
 // compute_pi(use_softmax=True) for node nd (MCTS_Gumbel.py:126-141 with :113-124, :99-103, :106-110).  Result f32 in S.pri.
 #ifndef GAZ_HOST_EMU
+// value of lane `i` (compile-time constant) in every lane: v_readlane_b32 into a scalar register (a few cycles) — __shfl would go
+// through the LDS crossbar (ds_bpermute, ~100 cycles of latency each, and these reductions are chains of them)
+GAZ_DEV uint32_t lane_val(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+GAZ_DEV float lane_val(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+GAZ_DEV double lane_val(double v, int i) {
+    const uint64_t b = det::d2bits(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, i), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), i);
+    return det::bits2d(((uint64_t)hi << 32) | lo);
+}
 // sum of v over lanes 0..n-1 in numpy's order for n < 8 (res = 0; res += a[i]), every lane gets the result
 template <class T> GAZ_DEV T seq_sum_lanes(T v, int n) {
     T res = (T)0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { const T vi = shfl(v, i); if (i < n) res = res + vi; }
+    for (int i = 0; i < 7; ++i) { const T vi = lane_val(v, i); if (i < n) res = res + vi; }
     return res;
 }
 template <class T> GAZ_DEV T max_lanes(T v, int n) {               // max over lanes 0..n-1 (n >= 1), starting from lane 0 like the loop it replaces
-    T m = shfl(v, 0);
+    T m = lane_val(v, 0);
 #pragma unroll
-    for (int i = 1; i < 7; ++i) { const T vi = shfl(v, i); if (i < n && vi > m) m = vi; }
+    for (int i = 1; i < 7; ++i) { const T vi = lane_val(v, i); if (i < n && vi > m) m = vi; }
     return m;
 }
 template <class T> GAZ_DEV T min_lanes(T v, int n) {
-    T m = shfl(v, 0);
+    T m = lane_val(v, 0);
 #pragma unroll
-    for (int i = 1; i < 7; ++i) { const T vi = shfl(v, i); if (i < n && vi < m) m = vi; }
+    for (int i = 1; i < 7; ++i) { const T vi = lane_val(v, i); if (i < n && vi < m) m = vi; }
     return m;
 }
 
@@ -123,7 +132,7 @@ template <class G> GAZ_DEV void compute_pi_small(const DevParams<G>& E, const No
     const float Wi = on ? nd.W()[i] : 0.0f, Li = on ? nd.P()[i] : 0.0f, RAWi = on ? RAW[i] : 0.0f;
     uint32_t nb = 0; uint64_t sumv = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { const uint32_t v = shfl(Ni, k); if (k < n) { if (v > nb) nb = v; sumv += v; } }
+    for (int k = 0; k < 7; ++k) { const uint32_t v = lane_val(Ni, k); if (k < n) { if (v > nb) nb = v; sumv += v; } }
     double x, mx, e, ssum;
     float pri;
     if (stable) {                                           // stablemax(float32 logits)
