@@ -217,7 +217,7 @@ template <class G> struct EngineT : gaz_engine {
         if (n <= 0) return fail("n_games must be positive");
         const bool gumbel = cfg.search == GAZ_SEARCH_GUMBEL;
         if (cfg.search != GAZ_SEARCH_PUCT && !gumbel) return fail("unknown search id");
-        E.c_visit = cfg.c_visit; E.c_scale = cfg.c_scale; E.gumbel_m = cfg.gumbel_m; E.g_stablemax = cfg.gumbel_stablemax;
+        E.c_visit = cfg.c_visit; E.c_scale = cfg.c_scale; E.gumbel_m = cfg.gumbel_m; E.g_stablemax = cfg.gumbel_stablemax; E.fast_find_win = cfg.fast_find_win;
         if (gumbel && (cfg.gumbel_m < 2 || cfg.run_iterations < 1)) return fail("Gumbel search needs m >= 2 and run_iterations >= 1");
         E.node_bytes = gumbel ? gumbel_node_bytes<G>() : NodeLayout<G>::SIZE;
         // re-root compaction: needed where a whole-game arena does not fit (Gomoku: 4.2 KB records); 0 = auto

@@ -35,7 +35,8 @@ constexpr float F32_EPS = 1.1920928955078125e-07f;
 
 // terminal moves in order of appearance (MCTS_Gumbel.py:301-318)
 template <class G> GAZ_DEV int terminal_probe_unsorted(const int8_t* board, const uint8_t* legal, int n_legal, int player,
-                                                       uint8_t* tact, uint8_t* twin, bool& any_win) {
+                                                       uint8_t* tact, uint8_t* twin, bool& any_win, bool fast_find_win = false) {
+    if (fast_find_win && first_win_only<G>(board, legal, n_legal, player, tact, twin)) { any_win = true; return 1; }
     const int empties = G::DRAWS ? count_empty<G>(board) : 0;
     int nt = 0; uint64_t anyw = 0;
     for (int base = 0; base < n_legal; base += WAVE) {
@@ -310,7 +311,7 @@ template <class G> GAZ_DEV bool g_root_pre(const DevParams<G>& E, int g, GameSta
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
     bool any_win;
-    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win);
+    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win, E.fast_find_win != 0);
     uint8_t h3[3];
     for (int i = 0; i < 3; ++i) h3[i] = (gs.n_hist - 1 - i >= 0) ? gs.hist[gs.n_hist - 1 - i] : 0;
     const int idx = alloc_node(E, ts);
@@ -371,7 +372,7 @@ template <class G> GAZ_DEV bool g_expand_pre(const DevParams<G>& E, int g, GameS
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
     bool any_win;
-    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win);
+    const int nt = terminal_probe_unsorted<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win, E.fast_find_win != 0);
     const int idx = alloc_node(E, ts);
     if (idx < 0) return false;
     NodeRef<G> nd = node_at(E, g, 0, idx);

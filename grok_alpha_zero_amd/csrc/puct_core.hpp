@@ -37,6 +37,7 @@ template <class G> struct DevParams {
     double c_init, c_base, alpha, eps;
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
     int32_t gumbel_m, node_bytes, compact;
+    int32_t fast_find_win;     // MCTS(fast_find_win=True): keep only the first winning move of a position (MCTS.py:282-283)
     int32_t g_stablemax;       // Gumbel: activation_fn = "stablemax" in deterministic_selection (Self_Play.py:69)
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
     int32_t tau_mode;          // -1: Self_Play's exploration schedule; 0 / 1: tau fixed by the caller (MCTS.update_hyperparams)
@@ -142,11 +143,29 @@ template <class G> GAZ_DEV int count_empty(const int8_t* board) {
     return n;
 }
 
+// fast_find_win (MCTS.py:282-283, MCTS_Gumbel.py:313): the scan stops at the first winning move in legal-action order.  Draws found
+// before it would be kept too, but a draw needs the last empty cell, i.e. a single legal move, so the result is that one move.
+template <class G> GAZ_DEV bool first_win_only(const int8_t* board, const uint8_t* legal, int n_legal, int player, uint8_t* tact, uint8_t* twin) {
+    for (int base = 0; base < n_legal; base += WAVE) {
+        const int i = base + lane_id();
+        const bool win = i < n_legal && wins_after<G>(board, landing_cell<G>(board, legal[i]), player);
+        const uint64_t m = ballot(win);
+        if (m) {
+            const int first = base + ffsll0(m);
+            if (lane_id() == 0) { tact[0] = legal[first]; twin[0] = 1; }
+            wave_sync();
+            return true;
+        }
+    }
+    return false;
+}
+
 // K3: which legal actions end the game for `player`?  One lane per candidate; result list is ordered the
 // way the reference orders it: stable ascending argsort of the 0/1 mask, reversed (MCTS.py:293-294 with the
 // documented tie rule) = wins in DESCENDING candidate order, then draws in descending candidate order.
 template <class G> GAZ_DEV int terminal_probe(const int8_t* board, const uint8_t* legal, int n_legal, int player,
-                                              uint8_t* tact, uint8_t* twin, bool& any_win) {
+                                              uint8_t* tact, uint8_t* twin, bool& any_win, bool fast_find_win = false) {
+    if (fast_find_win && first_win_only<G>(board, legal, n_legal, player, tact, twin)) { any_win = true; return 1; }
     const int empties = G::DRAWS ? count_empty<G>(board) : 0;
     int nt = 0;
     // pass 1: wins (descending), pass 2: draws (descending)
@@ -353,7 +372,7 @@ template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
     bool any_win;
-    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win);
+    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, gs.next_player, S.tact, S.twin, any_win, E.fast_find_win != 0);
     uint8_t h3[3];
     for (int i = 0; i < 3; ++i) h3[i] = (gs.n_hist - 1 - i >= 0) ? gs.hist[gs.n_hist - 1 - i] : 0;
     const int idx = alloc_node(E, ts);
@@ -544,7 +563,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
     bool any_win;
-    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win);
+    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, -mover, S.tact, S.twin, any_win, E.fast_find_win != 0);
     const int idx = alloc_node(E, ts);
     if (idx < 0) return false;
     NodeRef<G> nd = node_at(E, g, t, idx);

@@ -29,7 +29,7 @@ class EngineConfig(C.Structure):
                 ("device", C.c_int32), ("net_blocks", C.c_int32), ("net_filters", C.c_int32), ("policy_is_logits", C.c_int32),
                 ("gumbel_m", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double), ("compact_trees", C.c_int32),
                 ("single_tree", C.c_int32), ("n_opening", C.c_int32), ("opening_actions", C.c_int32 * 8),
-                ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32)]
+                ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32), ("fast_find_win", C.c_int32)]
 
 
 class Tensor(C.Structure):
@@ -100,7 +100,7 @@ class SelfPlayEngine:
                  create_new_root=False, sync_moves=False, nodes_per_tree=0, ring_capacity=None, slot_offset=0,
                  evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
                  policy_is_logits=False, max_tree_sims_per_wave=0, gumbel_m=0, c_visit=50.0, c_scale=1.0,
-                 compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, lib_path=None):
+                 compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, fast_find_win=False, lib_path=None):
         self.L = load_library(lib_path)
         self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
         self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
@@ -112,7 +112,7 @@ class SelfPlayEngine:
                                 int(use_dirichlet), int(create_new_root), int(sync_moves), nodes_per_tree, ring_capacity,
                                 seed, slot_offset, evaluator, hash_salt, device, net_blocks, net_filters, int(policy_is_logits),
                                 gumbel_m, c_visit, c_scale, compact_trees, int(single_tree), 0, (C.c_int32 * 8)(), (C.c_double * 8)(),
-                                max_tree_sims_per_wave, int(eval_cache_log2), int(gumbel_stablemax))
+                                max_tree_sims_per_wave, int(eval_cache_log2), int(gumbel_stablemax), int(fast_find_win))
         for i, (a, w) in enumerate(opening_actions or []):       # [(action index, weight)] — train_config["opening_actions"]
             self.cfg.opening_actions[i] = int(a); self.cfg.opening_weights[i] = float(w); self.cfg.n_opening = i + 1
         self.h = C.c_void_p()

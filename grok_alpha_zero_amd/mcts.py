@@ -7,7 +7,7 @@ simulation with a batch of one, exactly where the reference calls it.  `session=
 
 For throughput use `SelfPlayEngine` / `run_self_play` (thousands of games per launch); these classes exist so code written
 against the reference (`<Game>/play.py`, `Game_Tester.py:480-513`) keeps working.
-Not supported: `time_limit` (iteration limits only), `fast_find_win=True`; `use_njit` is ignored.
+Not supported: `time_limit` (iteration limits only); `use_njit` is ignored.
 """
 import os
 from warnings import warn
@@ -83,14 +83,13 @@ class MCTS(_EngineSearch):
     def __init__(self, game, session=None, use_njit=None, c_puct_init=2.5, c_puct_base=19_652, use_dirichlet=True,
                  dirichlet_alpha=1.11, dirichlet_epsilon=0.25, tau=1.0, fast_find_win=False, *, seed=None, hash_salt=0,
                  max_actions=None, lib_path=None):
-        if fast_find_win:
-            raise NotImplementedError("fast_find_win=True is not supported")
         self.c_puct_init, self.c_puct_base = c_puct_init, c_puct_base
         self.use_dirichlet, self.dirichlet_alpha, self.dirichlet_epsilon = use_dirichlet, dirichlet_alpha, dirichlet_epsilon
         self.tau = 0.0 if (tau != 0.0 and tau < 5e-3) else tau                          # MCTS.py:116-120
         self._attach(game, session, seed, lib_path, max_actions=max_actions or int(np.prod(game.board.shape)),
                      c_puct_init=c_puct_init, c_puct_base=c_puct_base, dirichlet_alpha=dirichlet_alpha,
-                     dirichlet_epsilon=dirichlet_epsilon, use_dirichlet=use_dirichlet, hash_salt=hash_salt, search=SEARCH_PUCT)
+                     dirichlet_epsilon=dirichlet_epsilon, use_dirichlet=use_dirichlet, hash_salt=hash_salt, search=SEARCH_PUCT,
+                     fast_find_win=bool(fast_find_win))
 
     def update_hyperparams(self, **kwargs):                                              # MCTS.py:134-168 (tau only; the rest is fixed at creation)
         tau = kwargs.get("tau")
@@ -121,15 +120,13 @@ class MCTS(_EngineSearch):
 class MCTS_Gumbel(_EngineSearch):
     def __init__(self, game, session, use_gumbel_noise=False, use_njit=None, m=16, c_visit=50.0, c_scale=0.1,
                  activation_fn="softmax", fast_find_win=False, *, seed=None, hash_salt=0, max_actions=None, lib_path=None):
-        if fast_find_win:
-            raise NotImplementedError("fast_find_win=True is not supported")
         if activation_fn not in ("softmax", "stablemax"):
             raise ValueError("activation_fn must be 'softmax' or 'stablemax'")
         if not use_gumbel_noise:
             warn("the engine always adds Gumbel noise at the root (Self_Play.py:64 uses use_gumbel_noise=True)")
         self.m, self.c_visit, self.c_scale = m, c_visit, c_scale
         self._attach(game, session, seed, lib_path, max_actions=max_actions or int(np.prod(game.board.shape)), hash_salt=hash_salt,
-                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale, gumbel_stablemax=activation_fn == "stablemax")
+                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale, gumbel_stablemax=activation_fn == "stablemax", fast_find_win=bool(fast_find_win))
 
     def update_hyperparams(self, *args, **kwargs):
         for k in ("m", "c_visit", "c_scale"):

@@ -76,6 +76,8 @@ typedef struct {
                                      A hit returns the bits the evaluator produced for the same input: results do not change */
     int32_t gumbel_stablemax;     /* 1: MCTS_Gumbel(activation_fn="stablemax") — build_config["use_stablemax"] (Self_Play.py:69):
                                      stablemax instead of softmax inside deterministic_selection (MCTS_Gumbel.py:144-148) */
+    int32_t fast_find_win;        /* MCTS(fast_find_win=True) (MCTS.py:88,282-283; MCTS_Gumbel.py:313): a position with a winning
+                                     move keeps only the first one (in legal-action order); Self_Play always passes False */
 } gaz_engine_config;
 
 typedef struct {

@@ -169,13 +169,16 @@ def test_hip_reroot_compaction_matches_oracle(oracle):
     eng.close()
 
 
-def test_hip_mcts_class_matches_reference_class(oracle):
-    """grok_alpha_zero_amd.mcts.MCTS on the GPU vs the fixture recorded from the reference's MCTS class (single tree)."""
+@pytest.mark.parametrize("name", ["c4_mcts_single", "c4_mcts_single_ffw"])
+def test_hip_mcts_class_matches_reference_class(oracle, name):
+    """grok_alpha_zero_amd.mcts.MCTS on the GPU vs the fixture recorded from the reference's MCTS class (single tree; _ffw:
+    constructed with fast_find_win=True)."""
     from grok_alpha_zero_amd.games import GAMES
     from grok_alpha_zero_amd.mcts import MCTS
-    fx = np.load(os.path.join(GOLDEN, "c4_mcts_single.npz"))
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
     game = GAMES["Connect4"]()
     mcts = MCTS(game, None, c_puct_init=float(fx["c_puct_init"]), dirichlet_alpha=float(fx["dirichlet_alpha"]), tau=1.0,
+                fast_find_win=bool(int(fx["fast_find_win"])) if "fast_find_win" in fx else False,
                 seed=int(fx["seed"]), hash_salt=int(fx["salt"]))
     for ply in range(len(fx["actions"])):
         mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)

@@ -30,7 +30,7 @@ class _HashSession:
         return [pol.reshape(1, -1), np.array([[val]], np.float32)]
 
 
-@pytest.mark.parametrize("name", ["c4_mcts_single", "ttt_mcts_single"])
+@pytest.mark.parametrize("name", ["c4_mcts_single", "ttt_mcts_single", "c4_mcts_single_ffw", "ttt_mcts_single_ffw"])
 @pytest.mark.parametrize("with_session", [True, False], ids=["session", "builtin"])
 def test_mcts_class_matches_reference_class(emu_lib, oracle, name, with_session):
     from grok_alpha_zero_amd.mcts import MCTS
@@ -39,7 +39,8 @@ def test_mcts_class_matches_reference_class(emu_lib, oracle, name, with_session)
     A = game.policy_shape[0]
     sess = _HashSession(oracle, A, int(fx["salt"])) if with_session else None
     mcts = MCTS(game, sess, c_puct_init=float(fx["c_puct_init"]), use_dirichlet=True, dirichlet_alpha=float(fx["dirichlet_alpha"]),
-                dirichlet_epsilon=0.25, tau=1.0, seed=int(fx["seed"]), hash_salt=int(fx["salt"]), lib_path=emu_lib)
+                dirichlet_epsilon=0.25, tau=1.0, fast_find_win=bool(int(fx["fast_find_win"])) if "fast_find_win" in fx else False,
+                seed=int(fx["seed"]), hash_salt=int(fx["salt"]), lib_path=emu_lib)
     for ply in range(len(fx["actions"])):
         mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
         move, rows = mcts.run(iteration_limit=int(fx["iteration_limit"]), use_bar=False)

@@ -104,7 +104,7 @@ PUCT_CASES = [
 ]
 
 
-def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, max_plies):
+def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, max_plies, fast_find_win=False):
     """The reference's MCTS class used on its own (Connect4/play.py, Game_Tester.py:480-513): ONE tree searches every move."""
     ref = ref_shim.load_reference()
     inj = ref_shim.activate(seed, 0, 0)
@@ -112,7 +112,7 @@ def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, 
     g = cls(); A = g.policy_shape[0]
     sess = ref_shim.HashSession(A, salt)
     mcts = ref["MCTS"].MCTS(g, sess, use_njit=False, c_puct_init=c_puct_init, use_dirichlet=True, dirichlet_alpha=alpha,
-                            dirichlet_epsilon=0.25, tau=1.0)
+                            dirichlet_epsilon=0.25, tau=1.0, fast_find_win=fast_find_win)
     acts, rN, rW, rP, rV = [], [], [], [], []
     for ply in range(max_plies):
         mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
@@ -127,10 +127,12 @@ def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, 
         mcts.prune_tree(move)
     return dict(game=game, iteration_limit=iteration_limit, c_puct_init=c_puct_init, dirichlet_alpha=alpha, seed=seed, salt=salt,
                 actions=np.array(acts, np.int32), root_N=np.array(rN), root_W=np.array(rW), root_P=np.array(rP),
-                root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls)
+                root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls, fast_find_win=int(fast_find_win))
 
 
-SINGLE_CASES = [("c4_mcts_single", "Connect4", 60, 2.5, 0.5, 21, 9, 42), ("ttt_mcts_single", "TicTacToe", 30, 1.25, 1.0, 22, 4, 9)]
+SINGLE_CASES = [("c4_mcts_single", "Connect4", 60, 2.5, 0.5, 21, 9, 42), ("ttt_mcts_single", "TicTacToe", 30, 1.25, 1.0, 22, 4, 9),
+                # fast_find_win=True (MCTS.py:88,282-283): a node with a winning move keeps only the first one
+                ("c4_mcts_single_ffw", "Connect4", 90, 2.5, 0.5, 23, 6, 42, True), ("ttt_mcts_single_ffw", "TicTacToe", 40, 1.25, 1.0, 24, 3, 9, True)]
 
 GUMBEL_CASES = [
     # name, game, MCTS_iteration_limit, max_actions, m, c_visit, c_scale, seed, slot, seq, salt
