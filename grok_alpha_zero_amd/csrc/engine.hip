@@ -165,6 +165,7 @@ struct gaz_engine {
     virtual int dominant(char*, int, double*) = 0;
     virtual int set_position(int, const int32_t*, int) = 0;
     virtual int set_search_params(int, int) = 0;
+    virtual int stop_search(int) = 0;
     virtual int start_search() = 0;
 };
 
@@ -565,6 +566,7 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
     int start_search() override { GAZ_LAUNCH(k_start_search<G>, E.n_games, WAVE, stream, E); HIP_OK(hipGetLastError()); return 0; }
+    int stop_search(int stop) override { E.stop_search = stop != 0; return 0; }
     int set_search_params(int run_iterations, int tau_mode) override {
         if (run_iterations > 0) E.run_iterations = run_iterations;
         E.tau_mode = tau_mode;
@@ -630,6 +632,7 @@ int gaz_engine_synchronize(gaz_engine* h) { return h->synchronize(); }
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable) { return h->timing_reset(enable); }
 int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions, int32_t n) { return h->set_position(slot, actions, n); }
 int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode) { return h->set_search_params(run_iterations, tau_mode); }
+int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(stop); }
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops) { return h->dominant(name, cap, flops); }
 int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }

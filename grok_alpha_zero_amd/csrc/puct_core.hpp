@@ -37,6 +37,7 @@ template <class G> struct DevParams {
     double c_init, c_base, alpha, eps;
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
     int32_t gumbel_m, node_bytes, compact;
+    int32_t stop_search;       // host clock expired (MCTS.run(time_limit), MCTS.py:560-563): finish the move now
     int32_t fast_find_win;     // MCTS(fast_find_win=True): keep only the first winning move of a position (MCTS.py:282-283)
     int32_t g_stablemax;       // Gumbel: activation_fn = "stablemax" in deterministic_selection (Self_Play.py:69)
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
@@ -846,7 +847,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             wave_sync();
         } else if (phase == PH_SIMS) {                                 // MCTS.run loop body (MCTS.py:560-587)
-            if (uni(gs.sims_done) >= uni(gs.iter_limit)) { if (lane_id() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
+            if (uni(gs.sims_done) >= uni(gs.iter_limit) || (E.stop_search && uni(gs.sims_done) > 0)) { if (lane_id() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
             const int t = uni(gs.runner);
             TreeState& ts = trees[t];
             NodeRef<G> r = node_at(E, g, t, ts.root);

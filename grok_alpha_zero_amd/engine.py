@@ -75,13 +75,14 @@ def load_library(lib_path=None):
     L.gaz_engine_timing_reset.argtypes = [H, C.c_int32]
     L.gaz_engine_set_position.argtypes = [H, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     L.gaz_engine_set_search_params.argtypes = [H, C.c_int32, C.c_int32]
+    L.gaz_engine_stop_search.argtypes = [H, C.c_int32]
     L.gaz_engine_start_search.argtypes = [H]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
-              "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search"):
+              "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -182,6 +183,9 @@ class SelfPlayEngine:
 
     def start_search(self):
         self._ck(self.L.gaz_engine_start_search(self.h))
+
+    def stop_search(self, stop=True):
+        self._ck(self.L.gaz_engine_stop_search(self.h, int(bool(stop))))
 
     def set_search_params(self, run_iterations=0, tau_mode=-1):
         self._ck(self.L.gaz_engine_set_search_params(self.h, int(run_iterations), int(tau_mode)))

@@ -7,7 +7,8 @@ simulation with a batch of one, exactly where the reference calls it.  `session=
 
 For throughput use `SelfPlayEngine` / `run_self_play` (thousands of games per launch); these classes exist so code written
 against the reference (`<Game>/play.py`, `Game_Tester.py:480-513`) keeps working.
-Not supported: `time_limit` (iteration limits only); `use_njit` is ignored.
+`time_limit` is honoured by `MCTS.run` (the host watches the clock, MCTS.py:560-563); `MCTS_Gumbel.run` maps it to the default
+iteration budget like the reference (MCTS_Gumbel.py:573-578).  `use_njit` is ignored.
 """
 import os
 from warnings import warn
@@ -50,23 +51,37 @@ class _EngineSearch:
         # the root (create_expand_root, MCTS.py:132) is built by the first run(): same evaluator call, same noise event
         self._eng.set_position(0, [_to_index(self._name, a) for a in game.action_history])
 
-    def _pump(self):
-        """Advance the engine until the game waits for the host; serve evaluator requests through session.run."""
+    def _pump(self, deadline=None):
+        """Advance the engine until the game waits for the host; serve evaluator requests through session.run.  `deadline`
+        (time.time() value): MCTS.run(time_limit=...) — when it passes, the search finishes its move at the next launch."""
+        import time
         eng = self._eng
         eng.start_search()
-        if self.session is None:
-            eng.run_move()
-            return
-        for _ in range(1_000_000):
-            x, pend = eng.read_batch()
-            if pend[0]:
-                policy, value = self.session.run(output_names=["policy", "value"],
-                                                 input_feed={"inputs": np.expand_dims(x[0].astype(np.float32), 0)})
-                eng.write_outputs(np.asarray(policy, np.float32).reshape(1, -1), np.asarray(value, np.float32).reshape(-1))
-            elif eng.root_stats()["phase"][0] in (PH_WAIT_HOST, PH_HALT, PH_IDLE):
+        stopped = False
+        try:
+            if self.session is None and deadline is None:
+                eng.run_move()
                 return
-            eng.wave_begin()
-        raise RuntimeError("search did not finish")
+            for _ in range(10_000_000):
+                if deadline is not None and not stopped and time.time() >= deadline:
+                    eng.stop_search(True); stopped = True
+                if self.session is None:
+                    eng.run_waves(4)
+                    if eng.root_stats()["phase"][0] in (PH_WAIT_HOST, PH_HALT, PH_IDLE):
+                        return
+                    continue
+                x, pend = eng.read_batch()
+                if pend[0]:
+                    policy, value = self.session.run(output_names=["policy", "value"],
+                                                     input_feed={"inputs": np.expand_dims(x[0].astype(np.float32), 0)})
+                    eng.write_outputs(np.asarray(policy, np.float32).reshape(1, -1), np.asarray(value, np.float32).reshape(-1))
+                elif eng.root_stats()["phase"][0] in (PH_WAIT_HOST, PH_HALT, PH_IDLE):
+                    return
+                eng.wave_begin()
+            raise RuntimeError("search did not finish")
+        finally:
+            if stopped:
+                eng.stop_search(False)
 
     def prune_tree(self, action, create_new_root=False):
         """game.do_action(action) was already called by the user (Self_Play.py:142-150); replay it on the device and re-root."""
@@ -80,6 +95,8 @@ class _EngineSearch:
 
 
 class MCTS(_EngineSearch):
+    _MAX_TIMED_ITERATIONS = 30_000               # one-game engines are created with a 32768-node arena per run() call
+
     def __init__(self, game, session=None, use_njit=None, c_puct_init=2.5, c_puct_base=19_652, use_dirichlet=True,
                  dirichlet_alpha=1.11, dirichlet_epsilon=0.25, tau=1.0, fast_find_win=False, *, seed=None, hash_salt=0,
                  max_actions=None, lib_path=None):
@@ -101,13 +118,20 @@ class MCTS(_EngineSearch):
 
     def run(self, iteration_limit=None, time_limit=None, use_bar=True):
         """-> (move, rows); row = [action, N / sum N, W / N, W, N, P, root.visits, is_terminal] sorted by visits (MCTS.py:591-618)."""
+        import time
         n_legal = len(self.game.get_legal_actions())
-        if iteration_limit is None or iteration_limit is True:
-            iteration_limit = 3 * n_legal                                                # MCTS.py:545-546
+        if time_limit is True:
+            time_limit = 30.0                                                            # MCTS.py:547-548
+        if n_legal == 1:
+            iteration_limit = 1                                                          # MCTS.py:543-544
+        elif time_limit is None and (iteration_limit is None or iteration_limit is True or iteration_limit < n_legal):
+            iteration_limit = 3 * n_legal                                                # MCTS.py:545-546 (None would never stop there)
+        if iteration_limit is None:
+            iteration_limit = self._MAX_TIMED_ITERATIONS                                 # time-limited only: bounded by the node arena
         if self.tau not in (0.0, 1.0):
             raise NotImplementedError("tau must be 0 or 1")
-        self._eng.set_search_params(int(iteration_limit), int(self.tau))
-        self._pump()
+        self._eng.set_search_params(int(min(iteration_limit, self._MAX_TIMED_ITERATIONS)), int(self.tau))
+        self._pump(None if time_limit is None else time.time() + float(time_limit))
         st = self._eng.root_stats()
         N, Wv, P, rv = st["N"][0], st["W"][0], st["P"][0], int(st["root_visits"][0])
         idx = [a for a in np.argsort(-P, kind="stable") if N[a] > 0 or P[a] > 0]        # child order = descending prior

@@ -22,6 +22,7 @@
  *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
  *   gaz_engine_set_position    MCTS.__init__ attaching to a live game object   MCTS.py:100,132,296-313
  *   gaz_engine_set_search_params  run(iteration_limit) / update_hyperparams(tau) MCTS.py:134-168,528
+ *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  */
 #ifndef GAZ_ENGINE_H
@@ -120,6 +121,9 @@ int gaz_engine_write_outputs(gaz_engine* h, const float* policy, const float* va
 int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions, int32_t n);
 /* iteration_limit of the following MCTS.run calls (<= 0: unchanged); tau_mode -1 = Self_Play schedule, 0 / 1 = fixed tau */
 int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode);
+/* MCTS.run(time_limit=...) (MCTS.py:528-563): stop != 0 makes every running search finish its move at the next launch, as the
+ * reference's `time.time() - start_time < time_limit` test does between iterations; stop = 0 re-arms.  The host owns the clock. */
+int gaz_engine_stop_search(gaz_engine* h, int32_t stop);
 
 /* sync + single_tree engines idle after set_position / apply_moves; this starts MCTS.run for the idle slots */
 int gaz_engine_start_search(gaz_engine* h);

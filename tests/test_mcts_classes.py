@@ -78,3 +78,24 @@ def test_mcts_gumbel_class_plays_the_self_play_fixture(emu_lib, oracle):
         game.do_action(move)
         mcts.prune_tree(move)
     mcts.close()
+
+
+def test_mcts_run_with_time_limit(emu_lib, oracle):
+    """MCTS.run(time_limit=...) (MCTS.py:528-563): the search stops when the host clock says so, the rows stay consistent, and an
+    iteration limit given together with it still caps the search."""
+    import time
+    from grok_alpha_zero_amd.mcts import MCTS
+    game = GAMES["Connect4"]()
+    mcts = MCTS(game, None, c_puct_init=2.5, dirichlet_alpha=0.5, tau=0.0, seed=3, hash_salt=1, lib_path=emu_lib)
+    t0 = time.time()
+    move, rows = mcts.run(iteration_limit=None, time_limit=0.2, use_bar=False)
+    dt = time.time() - t0
+    assert 0.15 <= dt < 5.0
+    visits = sum(int(r[4]) for r in rows)
+    assert visits >= 7 and rows == sorted(rows, key=lambda r: r[4], reverse=True)
+    assert int(move) == int(rows[0][0])                                       # tau = 0: the most visited move
+    game.do_action(move); mcts.prune_tree(move)
+    move2, rows2 = mcts.run(iteration_limit=40, time_limit=60.0, use_bar=False)   # the iteration limit ends it long before the clock
+    # the kept subtree carries its visits (MCTS.py:654): at most 40 new simulations on top of it
+    assert sum(int(r[4]) for r in rows2) <= 40 + visits
+    mcts.close()
