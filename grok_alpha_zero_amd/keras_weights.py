@@ -7,9 +7,10 @@ BatchNormalization: gamma, beta, moving_mean, moving_variance); a custom layer's
 (`layers/res_net__block_3/conv1/vars/0`, Net/ResNet/ResNet_Block.py:12-20).  Kernels are already in the layout net.py uses
 ([kh, kw, cin, cout] and [in, out]).
 
-`model.layers` of Connect4/Build_Model.py is sorted by depth; the two heads have the same depth profile, so within each class
-the policy layer precedes the value layer (it is created first) — that is the order assumed in ORDER below; the last Dense
-layers are additionally told apart by their output width.  PARITY UNPINNED: the reference ships no weight file and TensorFlow
+`model.layers` of a functional model is sorted by decreasing depth (distance to the branch's output), ties in the order the graph
+walk from outputs [policy, value] first met the layer — `_merge_heads` below restates that rule; for Connect4 and TicTacToe the two
+heads have the same length and simply alternate policy, value; for Gomoku (14 vs 17 layers) they interleave from the outputs
+backwards.  PARITY UNPINNED: the reference ships no weight file and TensorFlow
 is not installed here, so this mapping is checked only against files written by `save_keras_style` (same layout rules).
 """
 import re
@@ -18,25 +19,60 @@ import numpy as np
 import torch
 
 from . import h5io
-from .net import Connect4Net
+from .net import Connect4Net, GomokuNet, TicTacToeNet
 
 _VARS = {"conv": ("weight", "bias"), "dense": ("weight", "bias"), "bn": ("weight", "bias", "running_mean", "running_var")}
 
 
+def _merge_heads(policy, value):
+    """`model.layers` order of two heads that branch off the trunk (keras/src/ops/function.py map_graph): operations sorted by
+    decreasing depth — depth counts layers to the OUTPUT of the branch, so heads of unequal length interleave from their ends — and,
+    at equal depth, in the order the graph walk from outputs [policy, value] first met them (policy first).  Chains are lists of
+    (keras class, kind, module) from the trunk to the output; weightless layers (Activation, Reshape) count with kind None."""
+    ops = [(len(policy) - 1 - j, 0, j, e) for j, e in enumerate(policy)] + [(len(value) - 1 - j, 1, j, e) for j, e in enumerate(value)]
+    ops.sort(key=lambda t: (-t[0], t[1]))
+    return [e for _, _, _, e in ops if e[1] is not None]
+
+
+_ACT = ("activation", None, None)
+_RESH = ("reshape", None, None)
+
+
+def _trunk(net):
+    return [("conv2d", "conv", net.stem), ("batch_normalization", "bn", net.stem_bn)] + [("res_net__block", "block", b) for b in net.blocks]
+
+
 def _connect4_order(net):
-    """(keras class name, kind, module) in model.layers order for Connect4/Build_Model.py:19-80"""
-    o = [("conv2d", "conv", net.stem), ("batch_normalization", "bn", net.stem_bn)]
-    o += [("res_net__block", "block", b) for b in net.blocks]
-    o += [("conv2d", "conv", net.p_conv), ("conv2d", "conv", net.v_conv),
-          ("batch_normalization", "bn", net.p_bn0), ("batch_normalization", "bn", net.v_bn0),
-          ("dense", "dense", net.p_d1), ("dense", "dense", net.v_d1),
-          ("batch_normalization", "bn", net.p_bn1), ("batch_normalization", "bn", net.v_bn1),
-          ("dense", "dense", net.p_d2), ("dense", "dense", net.v_d2),
-          ("dense", "dense", net.p_d3), ("dense", "dense", net.v_d3)]
-    return o
+    """Connect4/Build_Model.py:19-80"""
+    p = [("conv2d", "conv", net.p_conv), _RESH, ("batch_normalization", "bn", net.p_bn0), _ACT, ("dense", "dense", net.p_d1),
+         ("batch_normalization", "bn", net.p_bn1), _ACT, ("dense", "dense", net.p_d2), ("dense", "dense", net.p_d3), _ACT]
+    v = [("conv2d", "conv", net.v_conv), _RESH, ("batch_normalization", "bn", net.v_bn0), _ACT, ("dense", "dense", net.v_d1),
+         ("batch_normalization", "bn", net.v_bn1), _ACT, ("dense", "dense", net.v_d2), ("dense", "dense", net.v_d3), _ACT]
+    return _trunk(net) + _merge_heads(p, v)
 
 
-ORDER = {Connect4Net: _connect4_order}
+def _gomoku_order(net):
+    """Gomoku/Build_Model.py:21-86 (heads of 14 and 17 layers: they interleave from the outputs backwards)"""
+    p = [("batch_normalization", "bn", net.p_bn0), _ACT, ("conv2d", "conv", net.p_c1), ("batch_normalization", "bn", net.p_bn1), _ACT,
+         ("conv2d", "conv", net.p_c2), _RESH, ("batch_normalization", "bn", net.p_bn2), _ACT, ("dense", "dense", net.p_d1),
+         ("batch_normalization", "bn", net.p_bn3), _ACT, ("dense", "dense", net.p_d2), _ACT]
+    v = [("batch_normalization", "bn", net.v_bn0), _ACT, ("conv2d", "conv", net.v_c1), ("batch_normalization", "bn", net.v_bn1), _ACT,
+         ("conv2d", "conv", net.v_c2), _RESH, ("batch_normalization", "bn", net.v_bn2), _ACT, ("dense", "dense", net.v_d1),
+         ("batch_normalization", "bn", net.v_bn3), _ACT, ("dense", "dense", net.v_d2), ("batch_normalization", "bn", net.v_bn4), _ACT,
+         ("dense", "dense", net.v_d3), _ACT]
+    return _trunk(net) + _merge_heads(p, v)
+
+
+def _tictactoe_order(net):
+    """TicTacToe/Build_Model.py:17-51"""
+    p = [("conv2d", "conv", net.p_conv), ("batch_normalization", "bn", net.p_bn), _RESH, ("dense", "dense", net.p_d1), _ACT,
+         ("dense", "dense", net.p_d2), ("dense", "dense", net.p_d3), _ACT]
+    v = [("conv2d", "conv", net.v_conv), ("batch_normalization", "bn", net.v_bn), _RESH, ("dense", "dense", net.v_d1),
+         ("dense", "dense", net.v_d2), _ACT, ("dense", "dense", net.v_d3), _ACT]
+    return _trunk(net) + _merge_heads(p, v)
+
+
+ORDER = {Connect4Net: _connect4_order, GomokuNet: _gomoku_order, TicTacToeNet: _tictactoe_order}
 
 
 def _groups(order):
@@ -68,7 +104,6 @@ def load_keras_weights(path, net):
     with h5io.H5File(path, "r") as f:
         have = set(f.walk("layers"))
         groups = _groups(ORDER[type(net)](net))
-        # the two last Dense layers: policy = the one with A outputs (only checked when both exist with different widths)
         with torch.no_grad():
             for g, kind, mod in groups:
                 for i, attr in enumerate(_VARS[kind]):

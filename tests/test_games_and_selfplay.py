@@ -238,3 +238,17 @@ def test_keras_weight_file_round_trip(tmp_path):
     assert torch.equal(pa, pb) and torch.equal(va, vb)
     with pytest.raises(KeyError):
         load_keras_weights(path, Connect4Net(4, seed=1))                     # a fourth block the file does not have
+    # the other two networks: unequal head lengths (Gomoku) and the 1x1 / 5x5 kernels (TicTacToe) through the same rules
+    from grok_alpha_zero_amd.net import GomokuNet, TicTacToeNet
+    for cls, kw in ((GomokuNet, dict(num_resnet_layers=2)), (TicTacToeNet, dict(num_resnet_layers=2))):
+        src2 = cls(seed=6, **kw).randomize_bn()
+        p2 = str(tmp_path / f"{cls.__name__}.weights.h5")
+        save_keras_style(src2, p2)
+        dst2 = load_keras_weights(p2, cls(seed=77, **kw))
+        a2, b2 = src2.export_engine_weights(), dst2.export_engine_weights()
+        for k in a2:
+            np.testing.assert_array_equal(np.asarray(a2[k]), np.asarray(b2[k]), err_msg=f"{cls.__name__} {k}")
+    with h5io.H5File(str(tmp_path / "GomokuNet.weights.h5"), "r") as f:
+        gn = f.walk("layers")
+    # Gomoku: the value head is three layers longer, so its first BN / conv come BEFORE the policy head's in model.layers
+    assert "layers/res_net__block/residual_conv/vars/0" in gn and "layers/batch_normalization_9/vars/0" in gn and "layers/dense_4/vars/1" in gn
