@@ -59,7 +59,7 @@ def _lib():
         ("H5Tget_class", C.c_int, [hid_t]), ("H5Tget_size", C.c_size_t, [hid_t]), ("H5Tget_sign", C.c_int, [hid_t]), ("H5Tclose", C.c_int, [hid_t]),
         ("H5Gget_info", C.c_int, [hid_t, C.POINTER(_GInfo)]), ("H5Gopen2", hid_t, [hid_t, C.c_char_p, hid_t]), ("H5Gclose", C.c_int, [hid_t]),
         ("H5Pset_create_intermediate_group", C.c_int, [hid_t, C.c_uint]), ("H5Eset_auto2", C.c_int, [hid_t, C.c_void_p, C.c_void_p]),
-        ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]),
+        ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]), ("H5Fflush", C.c_int, [hid_t, C.c_int]),
         ("H5Lget_name_by_idx", C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, C.c_char_p, C.c_size_t, hid_t]),
     ]:
         fn = getattr(L, f); fn.restype = res; fn.argtypes = args
@@ -105,6 +105,15 @@ class H5File:
         if self.fid >= 0:
             _lib().H5Fclose(self.fid)
             self.fid = -1
+
+    def n_links(self):
+        """number of links in the root group (O(1); listing the names of a large group is not)"""
+        info = _GInfo()
+        _lib().H5Gget_info(self.fid, C.byref(info))
+        return int(info.nlinks)
+
+    def flush(self):
+        _lib().H5Fflush(self.fid, 1)                               # H5F_SCOPE_GLOBAL
 
     def keys(self):
         L = _lib()

@@ -32,6 +32,7 @@ class ReplayStore:
             from . import h5io
             self.backend = "libhdf5" if h5io.available() else "npy"
         self.path = os.path.join(folder_path, "Self_Play_Data.h5" if self.backend != "npy" else "Self_Play_Data.npzdir")
+        self._f = None
 
     def _open(self, mode):
         if self.backend == "h5py":
@@ -58,17 +59,46 @@ class ReplayStore:
     def n_datasets(self):
         if self.backend == "npy":
             return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
+        if self._f is not None:
+            return self._f.n_links() - 1
         with self._open("r") as f:
-            return len(f.keys()) - 1
+            return f.n_links() - 1
+
+    # A generation appends thousands of games: `writing()` keeps ONE handle open for all of them (opening the file and counting its
+    # datasets per game made the writer, not the GPU, the limit: 0.3 s per game growing with the file), flushing every so often so
+    # that an interrupted run keeps what it wrote (the reference re-opens per game under a lock, Self_Play.py:178-208).
+    def writing(self, flush_every=256):
+        store = self
+
+        class _Session:
+            def __enter__(self_inner):
+                if store.backend != "npy":
+                    store._f = store._open("r+")
+                    store._stats = store._f.read("game_stats").astype(np.uint32)
+                    store._k0 = (store._f.n_links() - 1) // 3
+                store._flush_every, store._since_flush = flush_every, 0
+                return store
+
+            def __exit__(self_inner, *a):
+                if store._f is not None:
+                    store._f.close(); store._f = None
+                return False
+        return _Session()
 
     def append_game(self, boards_aug, policies_aug, values_aug, game_length, n_positions, winner):
         """One finished game: arrays [n_aug, T, ...] (Self_Play.py:174-208)."""
-        stats = self.game_stats().astype(np.uint32)
+        if self.backend != "npy" and self._f is None:
+            with self.writing():
+                return self.append_game(boards_aug, policies_aug, values_aug, game_length, n_positions, winner)
+        if self.backend == "npy":
+            stats = self.game_stats().astype(np.uint32)
+            k0 = self.n_datasets() // 3                               # dataset_name = (len(keys) - 1) // 3
+        else:
+            stats, k0 = self._stats, self._k0
         stats[0] = max(int(stats[0]), game_length)
         stats[1] += n_positions
         stats[2] += 1
         stats[winner + 4] += 1
-        k0 = self.n_datasets() // 3                                   # dataset_name = (len(keys) - 1) // 3
         if self.backend == "npy":
             np.save(os.path.join(self.path, "game_stats.npy"), stats)
             for inc in range(policies_aug.shape[0]):
@@ -76,12 +106,16 @@ class ReplayStore:
                 np.save(os.path.join(self.path, f"policies_{k0 + inc}.npy"), policies_aug[inc].astype(np.float32))
                 np.save(os.path.join(self.path, f"values_{k0 + inc}.npy"), values_aug[inc].astype(np.float32))
             return
-        with self._open("r+") as f:
-            f.write("game_stats", stats)
-            for inc in range(policies_aug.shape[0]):
-                f.create_dataset(f"boards_{k0 + inc}", boards_aug[inc], maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype)
-                f.create_dataset(f"policies_{k0 + inc}", policies_aug[inc], maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32)
-                f.create_dataset(f"values_{k0 + inc}", values_aug[inc], maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32)
+        f = self._f
+        f.write("game_stats", stats)
+        for inc in range(policies_aug.shape[0]):
+            f.create_dataset(f"boards_{k0 + inc}", boards_aug[inc], maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype)
+            f.create_dataset(f"policies_{k0 + inc}", policies_aug[inc], maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32)
+            f.create_dataset(f"values_{k0 + inc}", values_aug[inc], maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32)
+        self._k0 = k0 + policies_aug.shape[0]
+        self._since_flush += 1
+        if self._since_flush >= self._flush_every:
+            f.flush(); self._since_flush = 0
 
     def read(self, name):
         if self.backend == "npy":
@@ -105,6 +139,15 @@ class _H5pyAdapter:
 
     def keys(self):
         return list(self.f.keys())
+
+    def n_links(self):
+        return len(self.f)
+
+    def flush(self):
+        self.f.flush()
+
+    def close(self):
+        self.f.close()
 
     def create_dataset(self, name, data, maxshape=None, dtype=None):
         self.f.create_dataset(name, maxshape=maxshape, dtype=dtype, data=data, chunks=None)
@@ -173,6 +216,8 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     if use_net:
         eng.load_weights(weights)
     written = 0
+    session = store.writing()
+    session.__enter__()
     try:
         while written < games_left:
             eng.run_waves(64)
@@ -185,5 +230,6 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                 if progress:
                     progress(written, games_left)
     finally:
+        session.__exit__(None, None, None)
         eng.close()
     return written
