@@ -159,21 +159,62 @@ class _H5pyAdapter:
         return np.array(self.f[name])
 
 
+def _fast_states(name, actions):
+    """Input states of every ply of one game for the built-in plugins (games.py), without a Python call per ply: [T, H, W, C]
+    int8, equal to stacking game.get_input_state() before each move (checked against the plugin path in the tests)."""
+    T = len(actions)
+    if name == "Connect4":
+        boards = np.zeros((T + 1, 6, 7), np.int8)                     # boards[t] = position before move t
+        heights = [0] * 7
+        player = -1
+        for t, a in enumerate(actions):
+            a = int(a)
+            boards[t + 1] = boards[t]
+            boards[t + 1, 5 - heights[a], a] = player
+            heights[a] += 1; player = -player
+        st = np.zeros((T, 6, 7, 4), np.int8)
+        st[..., 3] = boards[:T]
+        if T > 2: st[2:, :, :, 2] = boards[1:T - 1]                   # one move back, once two moves were played
+        if T > 3: st[3:, :, :, 1] = boards[1:T - 2]
+        cur = np.where(np.arange(T) % 2 == 0, 1, -1).astype(np.int8)  # -next_player: the first mover is -1
+        st[..., 0] = cur[:, None, None]
+        if T > 4: st[4:, :, :, 0] = boards[1:T - 3]                   # >= 4 moves: the board three moves back (Connect4.py:340-345)
+        return st
+    W = 3 if name == "TicTacToe" else 15
+    boards = np.zeros((T + 1, W, W), np.int8)
+    player = -1
+    for t, a in enumerate(actions):
+        a = int(a)
+        boards[t + 1] = boards[t]
+        boards[t + 1, a // W, a % W] = player
+        player = -player
+    st = np.empty((T, W, W, 2), np.int8)
+    st[..., 1] = boards[:T]
+    st[..., 0] = np.where(np.arange(T) % 2 == 0, -1, 1).astype(np.int8)[:, None, None]   # -current_player = next_player... see games.py:118
+    return st
+
+
 def record_to_samples(game_class, rec):
     """Rebuild what Self_Play.play() collected for one finished game (Self_Play.py:80,114-127,159-175): input states by
     replaying the moves through the Game plugin, improved policies, values = 0.5 (z + q), then augment_sample."""
     game = game_class()
-    states = []
-    for idx in rec["actions"]:
-        states.append(np.array(game.get_input_state()).copy())
-        game.do_action(game_class.index_to_action(int(idx)) if hasattr(game_class, "index_to_action") else idx)
-    board_states = np.array(states, dtype=game.board.dtype)
+    from . import games as _builtin
+    if game_class in (_builtin.Connect4, _builtin.Gomoku, _builtin.TicTacToe):
+        board_states = _fast_states(game_class.ENGINE_NAME, rec["actions"])
+        n_plies = len(rec["actions"])
+    else:
+        states = []
+        for idx in rec["actions"]:
+            states.append(np.array(game.get_input_state()).copy())
+            game.do_action(game_class.index_to_action(int(idx)) if hasattr(game_class, "index_to_action") else idx)
+        board_states = np.array(states, dtype=game.board.dtype)
+        n_plies = len(game.action_history)
     policies = np.asarray(rec["policies"], np.float32)
     values = np.asarray(rec["values"], np.float32).reshape(-1, 1)
     aug_b, aug_p = game.augment_sample(board_states, policies)
     aug_b, aug_p = np.asarray(aug_b), np.asarray(aug_p)
     aug_v = np.repeat(values[None], aug_p.shape[0], axis=0)
-    return aug_b, aug_p, aug_v, len(game.action_history)
+    return aug_b, aug_p, aug_v, n_plies
 
 
 def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
@@ -219,9 +260,11 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     session = store.writing()
     session.__enter__()
     try:
+        eng.run_waves(64)
         while written < games_left:
-            eng.run_waves(64)
-            for rec in eng.drain_finished():
+            recs = eng.drain_finished()             # waits for the launches queued so far
+            eng.run_waves(64)                       # queue the next ones right away: the GPU works while the host converts and writes
+            for rec in recs:
                 if written >= games_left:
                     break
                 aug_b, aug_p, aug_v, length = record_to_samples(game_class, rec)

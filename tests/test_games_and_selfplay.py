@@ -252,3 +252,24 @@ def test_keras_weight_file_round_trip(tmp_path):
         gn = f.walk("layers")
     # Gomoku: the value head is three layers longer, so its first BN / conv come BEFORE the policy head's in model.layers
     assert "layers/res_net__block/residual_conv/vars/0" in gn and "layers/batch_normalization_9/vars/0" in gn and "layers/dense_4/vars/1" in gn
+
+
+def test_fast_state_reconstruction_matches_the_plugins():
+    """self_play._fast_states (no Python call per ply) == stacking game.get_input_state() before every move, all three games,
+    including Connect4's plane-0 switch after four moves (Connect4.py:340-345)."""
+    from grok_alpha_zero_amd.self_play import _fast_states
+    rng = np.random.default_rng(0)
+    for name in ("Connect4", "TicTacToe", "Gomoku"):
+        cls = GAMES[name]
+        for trial in range(25):
+            g = cls(); acts, states = [], []
+            while True:
+                legal = g.get_legal_actions()
+                if len(legal) == 0:
+                    break
+                a = legal[rng.integers(len(legal))]
+                states.append(np.array(g.get_input_state()).copy())
+                acts.append(cls.action_to_index(a)); g.do_action(a)
+                if g.check_win() != -2 or len(acts) >= 50:
+                    break
+            np.testing.assert_array_equal(np.array(states, np.int8), _fast_states(name, np.array(acts)), err_msg=f"{name} {trial}")
