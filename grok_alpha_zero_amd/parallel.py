@@ -28,3 +28,52 @@ def reduce_stats(local_counts, world_size, max_fields=()):
         for f in max_fields:
             out[f] = mm[f]
     return out
+
+
+def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, seed=0, weights=None, lib_path=None, **kw):
+    """`run_self_play` on every rank of an initialised torch.distributed job (one process per GPU; backend nccl = RCCL, or gloo):
+    the generation's missing games are split over the ranks, each rank plays its share into a private shard file with RNG streams
+    keyed by GLOBAL slot (rank r owns slots [r * n_games, (r + 1) * n_games)), then rank 0 appends the shards to
+    `folder_path/Self_Play_Data.h5` in rank order.  The only collectives are the broadcast of the number of missing games and the
+    all-reduce of the game_stats counters; no tree, evaluator or replay data crosses GPUs.  Returns the games written by all ranks."""
+    import os
+    import shutil
+    import torch.distributed as dist
+    from .self_play import ReplayStore, run_self_play
+    rank, world = dist.get_rank(), dist.get_world_size()
+    train_config = dict(configs[1])
+    main = ReplayStore(folder_path)
+    left = np.zeros(1, np.int64)
+    if rank == 0:
+        if not main.exists():
+            raise ValueError("Dataset file hasn't been created. Self play depends on that file!")
+        left[0] = max(0, int(train_config["games_per_generation"]) - int(main.game_stats()[2]))
+    left = reduce_stats(left, world)                                   # ranks > 0 contribute zeros: a broadcast through the one collective
+    games_left = int(left[0])
+    share = games_left // world + (1 if rank < games_left % world else 0)
+    generation = int(str(folder_path).rstrip("/").split("/")[-1])
+    shard_dir = os.path.join(folder_path, f".shard{rank}")
+    shutil.rmtree(shard_dir, ignore_errors=True)
+    shard = ReplayStore(shard_dir); shard.create()
+    device = kw.pop("device", int(os.environ.get("LOCAL_RANK", rank)) if dist.get_backend() == "nccl" else 0)
+    if share > 0:
+        run_self_play(game_class, (configs[0], dict(train_config, games_per_generation=share)) + tuple(configs[2:]), shard_dir,
+                      n_games=min(n_games, share), seed=seed, weights=weights, device=device, slot_offset=rank * n_games,
+                      lib_path=lib_path, generation=generation, **kw)
+    local = shard.game_stats().astype(np.int64)
+    total = reduce_stats(local, world, max_fields=(0,))                # game_stats: [longest game (max), plies, games, wins -1, draws, wins +1]
+    dist.barrier()
+    if rank == 0:
+        with main.writing():
+            for r in range(world):
+                sh = ReplayStore(os.path.join(folder_path, f".shard{r}"))
+                n_sets = sh.n_datasets() // 3
+                for k in range(n_sets):
+                    main.append_datasets(sh.read(f"boards_{k}"), sh.read(f"policies_{k}"), sh.read(f"values_{k}"))
+            before = main.game_stats().astype(np.int64)
+            merged = before + total; merged[0] = max(int(before[0]), int(total[0]))
+            main.set_game_stats(merged)
+        for r in range(world):
+            shutil.rmtree(os.path.join(folder_path, f".shard{r}"), ignore_errors=True)
+    dist.barrier()
+    return int(total[2])

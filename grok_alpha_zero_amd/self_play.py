@@ -117,6 +117,32 @@ class ReplayStore:
         if self._since_flush >= self._flush_every:
             f.flush(); self._since_flush = 0
 
+    def append_datasets(self, boards, policies, values):
+        """one (boards_k, policies_k, values_k) triple as the next k, without touching game_stats (shard merge, parallel.py)"""
+        if self.backend == "npy":
+            k = self.n_datasets() // 3
+            np.save(os.path.join(self.path, f"boards_{k}.npy"), boards); np.save(os.path.join(self.path, f"policies_{k}.npy"), policies)
+            np.save(os.path.join(self.path, f"values_{k}.npy"), values)
+            return
+        if self._f is None:
+            with self.writing():
+                return self.append_datasets(boards, policies, values)
+        k = self._k0
+        self._f.create_dataset(f"boards_{k}", boards, maxshape=(None, *boards.shape[1:]), dtype=boards.dtype)
+        self._f.create_dataset(f"policies_{k}", policies, maxshape=(None, *policies.shape[1:]), dtype=np.float32)
+        self._f.create_dataset(f"values_{k}", values, maxshape=(None, *values.shape[1:]), dtype=np.float32)
+        self._k0 = k + 1
+
+    def set_game_stats(self, stats):
+        stats = np.asarray(stats).astype(np.uint32)
+        if self.backend == "npy":
+            np.save(os.path.join(self.path, "game_stats.npy"), stats)
+            return
+        if self._f is None:
+            with self.writing():
+                return self.set_game_stats(stats)
+        self._f.write("game_stats", stats); self._stats = stats.copy()
+
     def read(self, name):
         if self.backend == "npy":
             return np.load(os.path.join(self.path, name + ".npy"))
@@ -218,7 +244,7 @@ def record_to_samples(game_class, rec):
 
 
 def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
-                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22):
+                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22, generation=None):
     """Generate `games_per_generation - game_stats[2]` self-play games into `folder_path` (Self_Play.py:259-272).
     `configs` = (build_config, train_config[, optimizer_config]).  `weights` = dict from net.export_engine_weights()
     (generation > 0); generation 0 (folder name "0") plays with the synthetic evaluator like the reference's
@@ -230,7 +256,8 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     games_left = int(train_config["games_per_generation"] - store.game_stats()[2])
     if games_left <= 0:
         return 0
-    generation = int(str(folder_path).rstrip("/").split("/")[-1])
+    if generation is None:
+        generation = int(str(folder_path).rstrip("/").split("/")[-1])                 # Self_Play.py:274
     name = getattr(game_class, "ENGINE_NAME", game_class.__name__)
     use_net = generation > 0 and weights is not None
     G = min(n_games, games_left)

@@ -273,3 +273,52 @@ def test_fast_state_reconstruction_matches_the_plugins():
                 if g.check_win() != -2 or len(acts) >= 50:
                     break
             np.testing.assert_array_equal(np.array(states, np.int8), _fast_states(name, np.array(acts)), err_msg=f"{name} {trial}")
+
+
+_SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from grok_alpha_zero_amd.games import GAMES
+from grok_alpha_zero_amd.parallel import run_self_play_sharded
+train = dict(games_per_generation=9, MCTS_iteration_limit=14, max_actions=9, num_explore_actions_first=2, num_explore_actions_second=1,
+             c_puct_init=1.25, dirichlet_alpha=1.0, use_gumbel=False)
+n = run_self_play_sharded(GAMES["TicTacToe"], ({}, train), sys.argv[3], n_games=3, seed=17, hash_salt=6, lib_path=sys.argv[2])
+assert n == 7, n                                                    # 9 wanted, 2 already in the file
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_self_play_two_ranks_gloo(tmp_path, oracle):
+    """parallel.run_self_play_sharded: two ranks play their share of a generation (that already holds 2 games) into private shards,
+    rank 0 merges them into the one Self_Play_Data.h5 the Dataloader expects; every merged game equals the oracle's game of its
+    GLOBAL slot, so the file does not depend on the number of ranks."""
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    emu = os.path.join(emu_dir, "libgaz_emu.so")
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    train2 = dict(games_per_generation=2, MCTS_iteration_limit=14, max_actions=9, num_explore_actions_first=2, num_explore_actions_second=1,
+                  c_puct_init=1.25, dirichlet_alpha=1.0, use_gumbel=False)
+    assert run_self_play(GAMES["TicTacToe"], ({}, train2), folder, n_games=2, seed=99, hash_salt=6, lib_path=emu) == 2
+    script = tmp_path / "shard_worker.py"; script.write_text(_SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, emu, folder], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    gs = store.game_stats()
+    assert gs[2] == 9 and gs[3] + gs[4] + gs[5] == 9 and store.n_datasets() == 9 * 8 * 3
+    assert not any(n.startswith(".shard") for n in os.listdir(folder))
+    # shard games: rank 0 plays 4 (slots 0-2 first), rank 1 plays 3 (slots 3-5); each is the oracle's game of that global slot
+    lengths = {}
+    for slot in range(6):
+        for seq in range(3):
+            o = oracle.selfplay_game("TicTacToe", 21, 9, 2, 1, 1.25, 1.0, 17, slot, seq, hash_salt=6)
+            lengths[(slot, seq)] = (o["T"], o["states"][:o["T"]])
+    merged = [store.read(f"boards_{k * 8}") for k in range(2, 9)]
+    for b in merged:
+        assert any(b.shape[0] == T and np.array_equal(b, st) for T, st in lengths.values())
+    assert sum(b.shape[0] for b in merged) + sum(store.read(f"boards_{k * 8}").shape[0] for k in range(2)) == gs[1]
