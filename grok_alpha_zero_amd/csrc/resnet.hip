@@ -23,6 +23,7 @@
 #include "conv3x3.hpp"
 #include "netops.hpp"
 #include "resblock.hpp"
+#include "trunk.hpp"
 
 namespace gaz {
 
@@ -462,6 +463,8 @@ struct ResNetEvaluator : Evaluator {
     bool fused = true;
     int stamp_calls = 0, n_cus = 256;
     bf16_t* stem_frag = nullptr;
+    bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
+    bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
     bool loaded = false;
@@ -511,6 +514,17 @@ struct ResNetEvaluator : Evaluator {
             if (!up_f32(b + ".bn1.scale", Fc) || !up_f32(b + ".bn1.shift", Fc) || !up_b16(b + ".conv1.w", 9LL * Fc * Fc) ||
                 !up_f32(b + ".conv1.scale", Fc) || !up_f32(b + ".conv1.shift", Fc) || !up_b16(b + ".conv2.w", 9LL * Fc * Fc) ||
                 !up_f32(b + ".conv2.bias", Fc)) return 1;
+        }
+        if (blocks > 0) {   // k_trunk operands: the slices of all blocks as one array, the per-block parameters as [block][5][128]
+            const size_t WB = 18 * (size_t)Fc * Fc;
+            trunk_w = dalloc<bf16_t>(blocks * WB); trunk_prm = dalloc<float>((size_t)blocks * TR_PRM);
+            if (!trunk_w || !trunk_prm) { *err = "hipMalloc"; return 1; }
+            for (int i = 0; i < blocks; ++i) {
+                const std::string b = "block" + std::to_string(i);
+                hipMemcpy(trunk_w + i * WB, b16[b + ".conv1.w"], WB * 2, hipMemcpyDeviceToDevice);     // conv2 sits right behind conv1
+                const char* names[5] = {".bn1.scale", ".bn1.shift", ".conv1.scale", ".conv1.shift", ".conv2.bias"};
+                for (int k = 0; k < 5; ++k) hipMemcpy(trunk_prm + ((size_t)i * 5 + k) * 128, f32[b + names[k]], 128 * 4, hipMemcpyDeviceToDevice);
+            }
         }
         if (!up_b16("heads.conv.w", 9LL * 32 * Fc) || !up_f32("heads.conv.bias", 32)) return 1;
         for (const char* pre : {"p", "v"}) {
@@ -564,7 +578,14 @@ struct ResNetEvaluator : Evaluator {
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
         bf16_t* cur = X;
-        for (int i = 0; fused && i < blocks; ++i) {             // one kernel per residual block (resblock.hpp)
+        const bool use_trunk = fused && trunk && blocks > 0 && HW <= 128;
+        if (use_trunk) {                            // every block in one kernel, k whole boards per workgroup (trunk.hpp)
+            TrunkArgs r; r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
+            r.tile_rows = (128 / HW) * HW;
+            hipLaunchKernelGGL((k_trunk<2, 8, 2>), dim3((M + r.tile_rows - 1) / r.tile_rows), dim3(TR_THREADS), trunk_lds_bytes<2>(), s, r);
+            cur = X2;
+        }
+        for (int i = 0; fused && !use_trunk && i < blocks; ++i) {             // one kernel per residual block (resblock.hpp)
             const std::string b = "block" + std::to_string(i);
             ResBlockArgs r; r.xin = cur; r.xout = cur == X ? X2 : X; r.w1 = b16[b + ".conv1.w"]; r.w2 = b16[b + ".conv2.w"];
             r.s1 = f32[b + ".bn1.scale"]; r.t1 = f32[b + ".bn1.shift"]; r.s2 = f32[b + ".conv1.scale"]; r.t2 = f32[b + ".conv1.shift"];
@@ -621,11 +642,12 @@ struct ResNetEvaluator : Evaluator {
     void timing_get(double* ms, int64_t* launches) override {
         double t = 0;
         for (size_t i = 0; i + 1 < tev.size(); i += 2) { float a = 0; hipEventElapsedTime(&a, tev[i], tev[i + 1]); t += a; }
-        *ms = t; *launches = (int64_t)(tev.size() / 2) * (fused ? 1 : 2) * blocks;
+        *ms = t; *launches = fused && trunk ? (int64_t)(tev.size() / 2) : (int64_t)(tev.size() / 2) * (fused ? 1 : 2) * blocks;
     }
     const char* dominant_kernel(int n, double* flops) override {
         const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
         *flops = fused ? 2 * conv : conv;
+        if (fused && trunk) { *flops = 2 * conv * blocks; return "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"; }
         return fused ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                      : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
@@ -936,6 +958,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->logits = cfg.policy_is_logits;
     const size_t M = (size_t)cfg.n_games * e->HW;
     e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
+    e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
@@ -945,6 +968,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
+    hipFuncSetAttribute((const void*)(k_trunk<2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes<2>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;

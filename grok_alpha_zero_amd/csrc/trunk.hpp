@@ -1,0 +1,235 @@
+// trunk.hpp — the WHOLE residual trunk (every 128 -> 128 pre-activation block, Net/ResNet/ResNet_Block.py:27-41 as stacked by
+// Connect4/Build_Model.py:25-29) as ONE kernel.  A convolution never looks across a board edge, so a tile made of whole boards
+// depends on nothing outside itself through ALL the blocks: a workgroup takes k boards, keeps their activations in LDS from the
+// stem output to the heads' input, and walks the blocks x 18 weight slices as one stream.  Against one k_resblock3 launch per
+// block this removes, per block: the image load and its wait, the pre-activation pass, the halo recomputation (Connect4:
+// 192 MFMA rows for 160 useful -> 128 for 126), the HBM round trip of x and the ramp / tail of a kernel boundary.
+//
+// Workgroup = 256 threads = 4 waves, wave (wm, wn) owns 32 TM board cells x 64 channels.  LDS: two swizzled bf16 images of
+// 64 TM rows x 128 channels — Xs, the raw residual stream x, and As, the operand of the running convolution
+// (relu(bn1(x)), then h = relu(bn2(conv1))) — one zero row for the board-edge taps, and two parameter sets (this block's
+// and the next one's).  70.9 KB at TM = 2: two workgroups per CU, one's barriers hide behind the other's MFMAs.
+//
+// The MFMA operands are SWAPPED against k_resblock3 (weights as A, cells as B): a lane's 16 accumulators are then 4 groups of
+// 4 consecutive CHANNELS of one cell, so h and x go back into the images as 8-byte LDS writes (4 per 32 x 32 tile instead of
+// 16 two-byte ones) and the epilogue needs no fp32 staging tile: residual read, + bias, new x, next block's pre-activation,
+// all at the lane's own image addresses.
+// Numerics are those of the per-block path bit for bit (x is rounded to bf16 between blocks there too, and the arithmetic
+// is written in the same order), which tests/test_evaluator_gpu.py checks.
+#pragma once
+#include "resblock.hpp"
+
+namespace gaz {
+
+struct TrunkArgs {
+    const bf16_t* xin; bf16_t* xout;              // [M][128] raw stream: stem output in, heads' input out
+    const bf16_t* w;                              // [nblocks][18 slices][8 k-steps][2][128][8], fragment order (arrange_conv_weights)
+    const float* prm;                             // [nblocks][5][128]: bn1 scale, bn1 shift, conv1 scale, conv1 shift (bn2 folded), conv2 bias
+    int M, H, W, nblocks;
+    int tile_rows;                                // k * H * W, k whole boards, <= 64 TM
+};
+constexpr int TR_THREADS = 256, TR_PRM = 5 * 128;
+template <int TM> constexpr size_t trunk_lds_bytes() { return (size_t)(2 * 64 * TM + 1) * 256 + 2 * TR_PRM * 4; }
+
+template <int TM, int RING, int OCC>
+__global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
+    constexpr int BN = 128, SLOTS = 16, TN = 2, KS = 8, ROWS = 64 * TM, ZROW = ROWS, BSL = BN * SLOTS;
+    static_assert(KS % RING == 0, "ring slot must not depend on the tap");
+    extern __shared__ uint4 lds[];
+    uint4* As = lds;                              // operand image, rows [0, ROWS) + the zero row
+    uint4* Xs = lds + (ROWS + 1) * SLOTS;         // raw stream
+    float* Ps = reinterpret_cast<float*>(Xs + ROWS * SLOTS);      // [2][5][128]
+    char* Ab = reinterpret_cast<char*>(As);
+    char* Xb = reinterpret_cast<char*>(Xs);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int HW = a.H * a.W;
+    const long m0 = (long)blockIdx.x * a.tile_rows;
+    const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
+    const int last_slice = a.nblocks * 18 - 1;
+
+    // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
+    constexpr int n_slots = ROWS * SLOTS;
+    for (int base = wave * 64; base < n_slots; base += TR_THREADS) {
+        const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+        long gr = m0 + lr;
+        gr = gr >= a.M ? (long)a.M - 1 : gr;
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(Xs + base), 16, 0, 0);
+    }
+    if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
+    const float4* prm4 = reinterpret_cast<const float4*>(a.prm);
+    float4* Ps4 = reinterpret_cast<float4*>(Ps);
+    if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
+
+    // B ring as in k_resblock3: fragment of global k-step g = slice * 8 + ks in bfr[g % RING]; the slices of ALL blocks are one array
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (last_slice + 1) * BSL * 16, 0x00020000);
+    const int col0 = wn * 64 + l31;                 // + 32 * tn: the channel this lane feeds into the weight operand
+    const int bvo = (lhi * BN + col0) * 16;
+    auto ldb = [&](int slice, int ks, int tn) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, ((slice * BSL) + ks * 2 * BN + tn * 32) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    uint4 bfr[RING][TN];
+#pragma unroll
+    for (int g = 0; g < RING; ++g)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = ldb(0, g, tn);
+
+    // per-lane geometry: cell lrow[tm] of the tile is this lane's column of the cell operand; 9 tap-validity bits
+    int lrow[TM]; unsigned vmask[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        lrow[tm] = (wm * TM + tm) * 32 + l31;
+        unsigned mm = 0;
+        if (lrow[tm] < a.tile_rows && m0 + lrow[tm] < a.M) {
+            const int cell = lrow[tm] % HW, y = cell / a.W, x = cell % a.W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
+            }
+        }
+        vmask[tm] = mm;
+    }
+    // byte offset of this lane's 8-byte group j (channels 8 (wn * 8 + tn * 4 + j) + 4 lhi ..+3) of cell lrow[tm] in either image
+    auto img_off = [&](int tm, int tn, int j) -> int {
+        const int row = lrow[tm], cslot = wn * 8 + tn * 4 + j;
+        return row * 256 + ((cslot ^ (row & 15)) << 4) + lhi * 8;
+    };
+    __syncthreads();                                // Xs, block 0's parameters and the zero row landed
+
+    // ---- block 0's operand: As = relu(x * s1 + t1)
+    {
+        const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;      // slot i = tid + 256 it keeps sp and (lr & 15)
+        float ps1[8], pt1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ps1[j] = Ps[tch0 + j]; pt1[j] = Ps[128 + tch0 + j]; }
+        for (int i = tid; i < n_slots; i += TR_THREADS) {
+            const uint4 v = Xs[i];
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = fmaxf(__uint_as_float(w[j] << 16) * ps1[2 * j] + pt1[2 * j], 0.0f);
+                const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * ps1[2 * j + 1] + pt1[2 * j + 1], 0.0f);
+                w[j] = pack_bf16(lo, hi);
+            }
+            As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll 1
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const float* P = Ps + (blk & 1) * TR_PRM;
+        const float* Pn = Ps + ((blk + 1) & 1) * TR_PRM;
+        const bool more = blk + 1 < a.nblocks;
+        float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (more && tid < TR_PRM / 4) pnext = prm4[(blk + 1) * (TR_PRM / 4) + tid];      // lands behind conv1
+#pragma unroll                                      // two copies of the tap loop: keeps the h-write address math out of any loop
+        for (int conv = 0; conv < 2; ++conv) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sl = blk * 18 + conv * 9 + tap;
+                const int nsl = sl < last_slice ? sl + 1 : sl;
+                const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+                int abase[TM], axor[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const bool ok = (vmask[tm] >> tap) & 1u;
+                    const int ar = ok ? lrow[tm] + off : ZROW;
+                    abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+                }
+                uint4 afr[2][TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cur = ks & 1, nxt = cur ^ 1;
+                    if (ks + 1 < KS) {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
+                    }
+                    bf16x8 bf[TN];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)     // D[channel][cell]: weights are the A operand
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[cur][tm]), acc[tm][tn], 0, 0, 0);
+                    if (ks + RING < KS) {
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
+                    } else {                        // next slice (the next conv's or the next block's); the very last one re-reads itself
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(nsl, ks + RING - KS, tn);
+                    }
+                }
+            }
+            if (conv == 0) {
+                if (more && tid < TR_PRM / 4) Ps4[((blk + 1) & 1) * (TR_PRM / 4) + tid] = pnext;
+                __syncthreads();                    // every wave is done with the operand image
+                // ---- h = relu(acc * s2 + t2) as bf16 over the operand image
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c0 = (wn * 8 + tn * 4 + j) * 8 + 4 * lhi;
+                            const float4 s = *reinterpret_cast<const float4*>(&P[2 * 128 + c0]);
+                            const float4 t = *reinterpret_cast<const float4*>(&P[3 * 128 + c0]);
+                            const float v0 = fmaxf(acc[tm][tn][4 * j + 0] * s.x + t.x, 0.0f), v1 = fmaxf(acc[tm][tn][4 * j + 1] * s.y + t.y, 0.0f);
+                            const float v2 = fmaxf(acc[tm][tn][4 * j + 2] * s.z + t.z, 0.0f), v3 = fmaxf(acc[tm][tn][4 * j + 3] * s.w + t.w, 0.0f);
+                            *reinterpret_cast<uint2*>(Ab + img_off(tm, tn, j)) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                        }
+                __syncthreads();
+            }
+        }
+        __syncthreads();                            // every wave is done with the h image
+        // ---- x = bf16(acc + bias + x) in place; the next block's operand relu(x * s1' + t1') over the operand image
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c0 = (wn * 8 + tn * 4 + j) * 8 + 4 * lhi, o = img_off(tm, tn, j);
+                    const float4 b = *reinterpret_cast<const float4*>(&P[4 * 128 + c0]);
+                    const uint2 xo = *reinterpret_cast<const uint2*>(Xb + o);
+                    const float v0 = (acc[tm][tn][4 * j + 0] + b.x) + __uint_as_float(xo.x << 16);
+                    const float v1 = (acc[tm][tn][4 * j + 1] + b.y) + __uint_as_float(xo.x & 0xFFFF0000u);
+                    const float v2 = (acc[tm][tn][4 * j + 2] + b.z) + __uint_as_float(xo.y << 16);
+                    const float v3 = (acc[tm][tn][4 * j + 3] + b.w) + __uint_as_float(xo.y & 0xFFFF0000u);
+                    const uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                    *reinterpret_cast<uint2*>(Xb + o) = xn;
+                    if (more) {
+                        const float4 s = *reinterpret_cast<const float4*>(&Pn[c0]);
+                        const float4 t = *reinterpret_cast<const float4*>(&Pn[128 + c0]);
+                        const float a0 = fmaxf(__uint_as_float(xn.x << 16) * s.x + t.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * s.y + t.y, 0.0f);
+                        const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t.w, 0.0f);
+                        *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+                    }
+                }
+        __syncthreads();
+    }
+
+    // ---- the tile's rows of x -> global, whole 256-byte rows
+    uint4* out4 = reinterpret_cast<uint4*>(a.xout);
+    for (int i = tid; i < a.tile_rows * SLOTS; i += TR_THREADS) {
+        const int lr = i / SLOTS, sp = i % SLOTS;
+        const long gr = m0 + lr;
+        if (gr < a.M) out4[gr * SLOTS + sp] = Xs[lr * SLOTS + (sp ^ (lr & 15))];
+    }
+}
+
+}  // namespace gaz

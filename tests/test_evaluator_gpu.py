@@ -79,6 +79,23 @@ def test_rows_are_batch_independent():
     eng.close()
 
 
+@pytest.mark.parametrize("blocks,n", [(1, 5), (6, 334), (3, 4096)])
+def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
+    """k_trunk (csrc/trunk.hpp: every residual block in one launch, activations resident in LDS) against one k_resblock3 launch
+    per block (GAZ_TRUNK=0): the same arithmetic in the same order => bit-exact outputs, ragged last tile included
+    (n not a multiple of the 3 boards a workgroup owns)."""
+    rng = np.random.default_rng(blocks + n)
+    x = _random_states(n, rng) if n < 1000 else rng.integers(-1, 2, size=(n, 6, 7, 4)).astype(np.int8)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GAZ_TRUNK", flag)
+        net, eng = _mk(max(n, 64), blocks, True, seed=3)
+        outs.append(eng.evaluate(x)[:2])
+        eng.close()
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
     """End-to-end: HIP search + HIP network vs the CPU oracle whose session.run is served by the SAME HIP network
     (evaluate() on one row) — visit counts bit-exact, so tree kernels and evaluator compose correctly."""
