@@ -581,8 +581,24 @@ struct ResNetEvaluator : Evaluator {
         const bool use_trunk = fused && trunk && blocks > 0 && HW <= 128;
         if (use_trunk) {                            // every block in one kernel, k whole boards per workgroup (trunk.hpp)
             TrunkArgs r; r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
-            r.tile_rows = (128 / HW) * HW;
-            hipLaunchKernelGGL((k_trunk<2, 8, 2>), dim3((M + r.tile_rows - 1) / r.tile_rows), dim3(TR_THREADS), trunk_lds_bytes<2>(), s, r);
+            r.tile_rows = (128 / HW) * HW; r.stamps = nullptr;
+            const int nwg = (M + r.tile_rows - 1) / r.tile_rows;
+            static const char* stamp_path = getenv("GAZ_TRUNK_STAMPS");    // diagnostic: phase stamps of the third launch -> file
+            const bool stamp = stamp_path && ++stamp_calls == 3;
+            if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * 128 * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * 128 * 8, s); }
+            static const int tv = getenv("GAZ_TRUNK_WN") ? atoi(getenv("GAZ_TRUNK_WN")) : 2;
+            static const int dbg = getenv("GAZ_TRUNK_DBG") ? atoi(getenv("GAZ_TRUNK_DBG")) : 0;
+            if (dbg == 1) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 1>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (dbg == 2) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (dbg == 3) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 3>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (tv == 4) hipLaunchKernelGGL((k_trunk<4, 4, 8, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            if (stamp) {
+                std::vector<unsigned long long> hst((size_t)nwg * 128);
+                hipStreamSynchronize(s);
+                hipMemcpy(hst.data(), r.stamps, hst.size() * 8, hipMemcpyDeviceToHost); hipFree(r.stamps);
+                if (FILE* f = fopen(stamp_path, "wb")) { fwrite(hst.data(), 8, hst.size(), f); fclose(f); }
+            }
             cur = X2;
         }
         for (int i = 0; fused && !use_trunk && i < blocks; ++i) {             // one kernel per residual block (resblock.hpp)
@@ -968,7 +984,11 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
-    hipFuncSetAttribute((const void*)(k_trunk<2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes<2>());
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<4, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;

@@ -27,13 +27,20 @@ struct TrunkArgs {
     const float* prm;                             // [nblocks][5][128]: bn1 scale, bn1 shift, conv1 scale, conv1 shift (bn2 folded), conv2 bias
     int M, H, W, nblocks;
     int tile_rows;                                // k * H * W, k whole boards, <= 64 TM
+    unsigned long long* stamps;                   // diagnostic (GAZ_TRUNK_STAMPS, tools/trunk_stamps.py): [workgroup][128] or null
 };
+// stamp i of wave 0: wall clock (100 MHz) at [i], shader clock at [64 + i].  0 start, 1 image landed, 2 block 0's operand ready,
+// 3 + 6 b + {0 conv1 taps, 1 barrier, 2 h written + barrier, 3 conv2 taps, 4 barrier, 5 epilogue + barrier} for b < 10, 63 end
+#define TR_STAMP(i) do { if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 128 + (i)] = wall_clock64(); a.stamps[(size_t)blockIdx.x * 128 + 64 + (i)] = clock64(); } } while (0)
 constexpr int TR_THREADS = 256, TR_PRM = 5 * 128;
-template <int TM> constexpr size_t trunk_lds_bytes() { return (size_t)(2 * 64 * TM + 1) * 256 + 2 * TR_PRM * 4; }
+constexpr size_t trunk_lds_bytes(int rows) { return (size_t)(2 * rows + 1) * 256 + 2 * TR_PRM * 4; }
 
-template <int TM, int RING, int OCC>
+// TM = 32-cell tiles per wave, WN = waves across the 128 channels (2: wave = 32 TM cells x 64 channels, two waves down the cells;
+// 4: wave = 32 TM cells x 32 channels, every wave all the cells of the tile — the workgroup then pulls each weight fragment from
+// L2 once instead of twice, for twice the LDS fragment reads per MFMA)
+template <int TM, int WN, int RING, int OCC, int DBG = 0>    // DBG (timing experiments, wrong results): 1 no weight refills, 2 no operand reads in the taps
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
-    constexpr int BN = 128, SLOTS = 16, TN = 2, KS = 8, ROWS = 64 * TM, ZROW = ROWS, BSL = BN * SLOTS;
+    constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
     extern __shared__ uint4 lds[];
     uint4* As = lds;                              // operand image, rows [0, ROWS) + the zero row
@@ -43,11 +50,12 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     char* Xb = reinterpret_cast<char*>(Xs);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lhi = lane >> 5;
     const int HW = a.H * a.W;
     const long m0 = (long)blockIdx.x * a.tile_rows;
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
     const int last_slice = a.nblocks * 18 - 1;
+    TR_STAMP(0);
 
     // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
     constexpr int n_slots = ROWS * SLOTS;
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     // B ring as in k_resblock3: fragment of global k-step g = slice * 8 + ks in bfr[g % RING]; the slices of ALL blocks are one array
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (last_slice + 1) * BSL * 16, 0x00020000);
-    const int col0 = wn * 64 + l31;                 // + 32 * tn: the channel this lane feeds into the weight operand
+    const int col0 = wn * (32 * TN) + l31;          // + 32 * tn: the channel this lane feeds into the weight operand
     const int bvo = (lhi * BN + col0) * 16;
     auto ldb = [&](int slice, int ks, int tn) -> uint4 {
         const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo, ((slice * BSL) + ks * 2 * BN + tn * 32) * 16, 0);
@@ -93,12 +101,13 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         }
         vmask[tm] = mm;
     }
-    // byte offset of this lane's 8-byte group j (channels 8 (wn * 8 + tn * 4 + j) + 4 lhi ..+3) of cell lrow[tm] in either image
+    // byte offset of this lane's 8-byte group j (channels 8 cslot + 4 lhi ..+3, cslot = (wn TN + tn) 4 + j) of cell lrow[tm] in either image
     auto img_off = [&](int tm, int tn, int j) -> int {
-        const int row = lrow[tm], cslot = wn * 8 + tn * 4 + j;
+        const int row = lrow[tm], cslot = (wn * TN + tn) * 4 + j;
         return row * 256 + ((cslot ^ (row & 15)) << 4) + lhi * 8;
     };
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
+    TR_STAMP(1);
 
     // ---- block 0's operand: As = relu(x * s1 + t1)
     {
@@ -119,6 +128,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         }
     }
     __syncthreads();
+    TR_STAMP(2);
 
     f32x16 acc[TM][TN];
 #pragma unroll 1
@@ -136,28 +146,39 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                const int sl = blk * 18 + conv * 9 + tap;
-                const int nsl = sl < last_slice ? sl + 1 : sl;
+            // Cell-operand fragments: four register buffers, k-step ks in afr[ks % 4], fetched THREE k-steps ahead and across the
+            // tap boundary (the last three k-steps of a tap fetch the next tap's first three), so no MFMA waits on an LDS
+            // round trip.  __builtin_amdgcn_sched_barrier pins each k-step's reads, MFMAs and weight loads where they are
+            // written: left alone, the scheduler sinks every ds_read to just before its MFMA and the ring's loads to the end of
+            // the tap (both latencies fully exposed: a lone wave ran the taps at 50 % of the MFMA rate).
+            int pb[TM], pbn[TM];                    // byte address of k-slot 0 of this lane's operand row: row * 256 | ((lhi ^ row & 15) << 4)
+            auto tap_rows = [&](int tap, int (&o)[TM]) {
                 const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
-                int abase[TM], axor[TM];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     const bool ok = (vmask[tm] >> tap) & 1u;
                     const int ar = ok ? lrow[tm] + off : ZROW;
-                    abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
+                    o[tm] = ar * 256 + ((lhi ^ (ar & 15)) << 4);
                 }
-                uint4 afr[2][TM];
+            };
+            uint4 afr[4][TM];
+            tap_rows(0, pb);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) afr[d][tm] = *reinterpret_cast<const uint4*>(Ab + (pb[tm] ^ (d * 32)));
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sl = blk * 18 + conv * 9 + tap;
+                const int nsl = sl < last_slice ? sl + 1 : sl;
+                tap_rows(tap < 8 ? tap + 1 : 8, pbn);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int cur = ks & 1, nxt = cur ^ 1;
-                    if (ks + 1 < KS) {
+                    if (!(DBG & 2))
 #pragma unroll
-                        for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
-                    }
+                    for (int tm = 0; tm < TM; ++tm)
+                        afr[(ks + 3) % 4][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + 3 < KS ? pb[tm] : pbn[tm]) ^ (((ks + 3) % KS) * 32)));
                     bf16x8 bf[TN];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
@@ -165,19 +186,25 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)     // D[channel][cell]: weights are the A operand
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[cur][tm]), acc[tm][tn], 0, 0, 0);
-                    if (ks + RING < KS) {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[ks % 4][tm]), acc[tm][tn], 0, 0, 0);
+                    if (DBG & 1) {
+                    } else if (ks + RING < KS) {
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
                     } else {                        // next slice (the next conv's or the next block's); the very last one re-reads itself
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(nsl, ks + RING - KS, tn);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) pb[tm] = pbn[tm];
             }
+            if (blk < 10) TR_STAMP(3 + 6 * blk + 3 * conv);
             if (conv == 0) {
                 if (more && tid < TR_PRM / 4) Ps4[((blk + 1) & 1) * (TR_PRM / 4) + tid] = pnext;
                 __syncthreads();                    // every wave is done with the operand image
+                if (blk < 10) TR_STAMP(4 + 6 * blk);
                 // ---- h = relu(acc * s2 + t2) as bf16 over the operand image
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int c0 = (wn * 8 + tn * 4 + j) * 8 + 4 * lhi;
+                            const int c0 = ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi;
                             const float4 s = *reinterpret_cast<const float4*>(&P[2 * 128 + c0]);
                             const float4 t = *reinterpret_cast<const float4*>(&P[3 * 128 + c0]);
                             const float v0 = fmaxf(acc[tm][tn][4 * j + 0] * s.x + t.x, 0.0f), v1 = fmaxf(acc[tm][tn][4 * j + 1] * s.y + t.y, 0.0f);
@@ -193,9 +220,11 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                             *reinterpret_cast<uint2*>(Ab + img_off(tm, tn, j)) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
                         }
                 __syncthreads();
+                if (blk < 10) TR_STAMP(5 + 6 * blk);
             }
         }
         __syncthreads();                            // every wave is done with the h image
+        if (blk < 10) TR_STAMP(7 + 6 * blk);
         // ---- x = bf16(acc + bias + x) in place; the next block's operand relu(x * s1' + t1') over the operand image
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -203,7 +232,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int c0 = (wn * 8 + tn * 4 + j) * 8 + 4 * lhi, o = img_off(tm, tn, j);
+                    const int c0 = ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi, o = img_off(tm, tn, j);
                     const float4 b = *reinterpret_cast<const float4*>(&P[4 * 128 + c0]);
                     const uint2 xo = *reinterpret_cast<const uint2*>(Xb + o);
                     const float v0 = (acc[tm][tn][4 * j + 0] + b.x) + __uint_as_float(xo.x << 16);
@@ -221,6 +250,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                     }
                 }
         __syncthreads();
+        if (blk < 10) TR_STAMP(8 + 6 * blk);
     }
 
     // ---- the tile's rows of x -> global, whole 256-byte rows
@@ -230,6 +260,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         const long gr = m0 + lr;
         if (gr < a.M) out4[gr * SLOTS + sp] = Xs[lr * SLOTS + (sp ^ (lr & 15))];
     }
+    TR_STAMP(63);
 }
 
 }  // namespace gaz
