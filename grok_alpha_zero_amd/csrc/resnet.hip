@@ -125,18 +125,6 @@ struct StemMArgs {
     int M, H, W, tiles_per_wave;
 };
 
-__device__ __forceinline__ float gelu_as(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
-    float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    p = 0.5f * p * __expf(-x * x);                 // 0.5 * erfc(x)
-    return v * (v < 0.0f ? p : 1.0f - p);
-}
-
-__device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two small integers -> packed bf16 (exact)
-    return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
-}
-
 // CIN input planes (2: Gomoku, 4: Connect4), COUT channels, k = tap * CIN + plane padded to KST k-steps of 16; operand
 // k-steps [0, KST) carry the hi halves of the weights, [KST, 2 KST) the lo halves, against the same activations.
 template <int CIN> constexpr int stem_ksteps() { return (9 * CIN + 15) / 16; }
@@ -463,6 +451,7 @@ struct ResNetEvaluator : Evaluator {
     bool fused = true;
     int stamp_calls = 0, n_cus = 256;
     bf16_t* stem_frag = nullptr;
+    bool trunk_whole = true;                        // ... including the stem and the heads' first convolution; GAZ_TRUNK_WHOLE=0 -> k_stem_mfma / k_conv_heads
     bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
     bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
@@ -566,7 +555,10 @@ struct ResNetEvaluator : Evaluator {
         StemArgs st; st.in = in; st.w = f32["stem.w"]; st.scale = f32["stem.scale"]; st.shift = f32["stem.shift"];
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
         st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
-        if (fused) {
+        const bool use_trunk = fused && trunk && blocks > 0 && HW <= 128;
+        const bool whole = use_trunk && trunk_whole;     // stem and heads' first convolution inside k_trunk as well
+        if (whole) {
+        } else if (fused) {
             StemMArgs sm; memset(&sm, 0, sizeof(sm)); sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = f32["stem.shift"]; sm.out = X;
             sm.M = M; sm.H = H; sm.W = W;
             const int tiles = (M + 31) / 32;
@@ -578,21 +570,18 @@ struct ResNetEvaluator : Evaluator {
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
         bf16_t* cur = X;
-        const bool use_trunk = fused && trunk && blocks > 0 && HW <= 128;
         if (use_trunk) {                            // every block in one kernel, k whole boards per workgroup (trunk.hpp)
-            TrunkArgs r; r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
+            TrunkArgs r; memset(&r, 0, sizeof(r)); r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
             r.tile_rows = (128 / HW) * HW; r.stamps = nullptr;
+            r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
+            r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
+            r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"]; r.p_feat = pfeat; r.v_feat = vfeat;
             const int nwg = (M + r.tile_rows - 1) / r.tile_rows;
             static const char* stamp_path = getenv("GAZ_TRUNK_STAMPS");    // diagnostic: phase stamps of the third launch -> file
             const bool stamp = stamp_path && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * 128 * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * 128 * 8, s); }
-            static const int tv = getenv("GAZ_TRUNK_WN") ? atoi(getenv("GAZ_TRUNK_WN")) : 2;
-            static const int dbg = getenv("GAZ_TRUNK_DBG") ? atoi(getenv("GAZ_TRUNK_DBG")) : 0;
-            if (dbg == 1) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 1>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
-            else if (dbg == 2) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
-            else if (dbg == 3) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, 3>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
-            else if (tv == 4) hipLaunchKernelGGL((k_trunk<4, 4, 8, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
-            else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            if (whole) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             if (stamp) {
                 std::vector<unsigned long long> hst((size_t)nwg * 128);
                 hipStreamSynchronize(s);
@@ -636,7 +625,7 @@ struct ResNetEvaluator : Evaluator {
                        last ? nullptr : f32[nb + ".bn1.scale"], last ? nullptr : f32[nb + ".bn1.shift"], last ? nullptr : Aa, M);
         }
         if (timing) hipEventRecord(e1, s);
-        {   // first conv of both heads + flat BN + ReLU (k_conv_heads)
+        if (!whole) {   // first conv of both heads + flat BN + ReLU (k_conv_heads)
             HeadsConvArgs hc; hc.in = cur; hc.wgt = b16["heads.conv.w"]; hc.bias = f32["heads.conv.bias"];
             hc.p_fs = f32["p.bn0.scale"]; hc.p_ft = f32["p.bn0.shift"]; hc.v_fs = f32["v.bn0.scale"]; hc.v_ft = f32["v.bn0.shift"];
             hc.p_feat = pfeat; hc.v_feat = vfeat; hc.M = M; hc.H = H; hc.W = W;
@@ -975,6 +964,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     const size_t M = (size_t)cfg.n_games * e->HW;
     e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
+    e->trunk_whole = !(getenv("GAZ_TRUNK_WHOLE") && atoi(getenv("GAZ_TRUNK_WHOLE")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
@@ -984,11 +974,8 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_resblock, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
-    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
-    hipFuncSetAttribute((const void*)(k_trunk<4, 4, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
-    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
-    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
-    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;

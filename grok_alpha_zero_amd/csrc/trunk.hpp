@@ -28,7 +28,23 @@ struct TrunkArgs {
     int M, H, W, nblocks;
     int tile_rows;                                // k * H * W, k whole boards, <= 64 TM
     unsigned long long* stamps;                   // diagnostic (GAZ_TRUNK_STAMPS, tools/trunk_stamps.py): [workgroup][128] or null
+    // STEM: the stem convolution (k_stem_mfma's operands) computed straight into the images instead of reading xin
+    const int8_t* planes; const uint4* stem_frag; const float* stem_shift;        // [M][4] int8; [6 k-steps][2][128] x 8 bf16 (hi | lo); [128]
+    // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
+    const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
+    const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
 };
+
+__device__ __forceinline__ float gelu_as(float v) {         // x * Phi(x), Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8)
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    p = 0.5f * p * __expf(-x * x);                 // 0.5 * erfc(x)
+    return v * (v < 0.0f ? p : 1.0f - p);
+}
+__device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two small integers -> packed bf16 (exact)
+    return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+}
 // stamp i of wave 0: wall clock (100 MHz) at [i], shader clock at [64 + i].  0 start, 1 image landed, 2 block 0's operand ready,
 // 3 + 6 b + {0 conv1 taps, 1 barrier, 2 h written + barrier, 3 conv2 taps, 4 barrier, 5 epilogue + barrier} for b < 10, 63 end
 #define TR_STAMP(i) do { if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 128 + (i)] = wall_clock64(); a.stamps[(size_t)blockIdx.x * 128 + 64 + (i)] = clock64(); } } while (0)
@@ -38,7 +54,7 @@ constexpr size_t trunk_lds_bytes(int rows) { return (size_t)(2 * rows + 1) * 256
 // TM = 32-cell tiles per wave, WN = waves across the 128 channels (2: wave = 32 TM cells x 64 channels, two waves down the cells;
 // 4: wave = 32 TM cells x 32 channels, every wave all the cells of the tile — the workgroup then pulls each weight fragment from
 // L2 once instead of twice, for twice the LDS fragment reads per MFMA)
-template <int TM, int WN, int RING, int OCC, int DBG = 0>    // DBG (timing experiments, wrong results): 1 no weight refills, 2 no operand reads in the taps
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
@@ -57,18 +73,21 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     const int last_slice = a.nblocks * 18 - 1;
     TR_STAMP(0);
 
-    // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
     constexpr int n_slots = ROWS * SLOTS;
+    if (!STEM) {
+    // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
     for (int base = wave * 64; base < n_slots; base += TR_THREADS) {
         const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
         long gr = m0 + lr;
         gr = gr >= a.M ? (long)a.M - 1 : gr;
         __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(Xs + base), 16, 0, 0);
     }
+    }
     if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
     const float4* prm4 = reinterpret_cast<const float4*>(a.prm);
     float4* Ps4 = reinterpret_cast<float4*>(Ps);
     if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
+    if (STEM && tid < 32) Ps4[TR_PRM / 4 + tid] = reinterpret_cast<const float4*>(a.stem_shift)[tid];      // the idle parameter set holds the stem's shift
 
     // B ring as in k_resblock3: fragment of global k-step g = slice * 8 + ks in bfr[g % RING]; the slices of ALL blocks are one array
     typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -109,6 +128,66 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
     TR_STAMP(1);
 
+    f32x16 acc[TM][TN];
+    if (STEM) {
+        // ---- stem (Connect4/Build_Model.py:22-24: Conv3x3 4 -> 128, BN, GELU) as in k_stem_mfma: k = tap * 4 + plane padded to 48, the
+        // fp32 weights (BN scale folded in) as bf16 hi + lo halves against the same exact int8 activations; x and block 0's operand
+        // go straight into the images
+        static_assert(!STEM || TN == 2, "stem epilogue is written for the 2 x 2 wave tile");
+        const int* in32 = reinterpret_cast<const int*>(a.planes);
+        uint4 sw[6][TN];
+#pragma unroll
+        for (int ks2 = 0; ks2 < 6; ++ks2)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) sw[ks2][tn] = a.stem_frag[(ks2 * 2 + lhi) * 128 + col0 + tn * 32];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const long gr = m0 + lrow[tm];
+            const bool rok = lrow[tm] < a.tile_rows && gr < a.M;
+            uint4 cf[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                int pl[8];                          // this lane's 8 activations: taps 4 ks + 2 lhi + {0, 1}, 4 planes each
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tap = ks * 4 + lhi * 2 + h;
+                    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                    int packed = 0;
+                    if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u)) packed = in32[gr + dy * a.W + dx];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pl[h * 4 + c] = (int)(int8_t)((packed >> (8 * c)) & 0xFF);
+                }
+                cf[ks] = make_uint4(s8x2_to_bf16x2(pl[0], pl[1]), s8x2_to_bf16x2(pl[2], pl[3]), s8x2_to_bf16x2(pl[4], pl[5]), s8x2_to_bf16x2(pl[6], pl[7]));
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+#pragma unroll
+                for (int ks2 = 0; ks2 < 6; ++ks2)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&sw[ks2][tn]), *reinterpret_cast<const bf16x8*>(&cf[ks2 % 3]), acc[tm][tn], 0, 0, 0);
+            }
+        }
+        const float* SH = Ps + TR_PRM;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c0 = ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi, o = img_off(tm, tn, j);
+                    const float4 sh = *reinterpret_cast<const float4*>(&SH[c0]);
+                    const float4 s = *reinterpret_cast<const float4*>(&Ps[c0]);
+                    const float4 t = *reinterpret_cast<const float4*>(&Ps[128 + c0]);
+                    const float v0 = gelu_as(acc[tm][tn][4 * j + 0] + sh.x), v1 = gelu_as(acc[tm][tn][4 * j + 1] + sh.y);
+                    const float v2 = gelu_as(acc[tm][tn][4 * j + 2] + sh.z), v3 = gelu_as(acc[tm][tn][4 * j + 3] + sh.w);
+                    const uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                    *reinterpret_cast<uint2*>(Xb + o) = xn;
+                    const float a0 = fmaxf(__uint_as_float(xn.x << 16) * s.x + t.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * s.y + t.y, 0.0f);
+                    const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t.w, 0.0f);
+                    *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+                }
+    } else {
     // ---- block 0's operand: As = relu(x * s1 + t1)
     {
         const int tch0 = ((tid % SLOTS) ^ ((tid / SLOTS) & 15)) * 8;      // slot i = tid + 256 it keeps sp and (lr & 15)
@@ -127,10 +206,10 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
             As[i] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    }
     __syncthreads();
     TR_STAMP(2);
 
-    f32x16 acc[TM][TN];
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -175,7 +254,6 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (!(DBG & 2))
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
                         afr[(ks + 3) % 4][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + 3 < KS ? pb[tm] : pbn[tm]) ^ (((ks + 3) % KS) * 32)));
@@ -187,8 +265,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)     // D[channel][cell]: weights are the A operand
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[ks % 4][tm]), acc[tm][tn], 0, 0, 0);
-                    if (DBG & 1) {
-                    } else if (ks + RING < KS) {
+                    if (ks + RING < KS) {
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
                     } else {                        // next slice (the next conv's or the next block's); the very last one re-reads itself
@@ -253,12 +330,69 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         if (blk < 10) TR_STAMP(8 + 6 * blk);
     }
 
+    if (HEADS) {
+        // ---- first convolution of both heads (Connect4/Build_Model.py:41,62: two Conv3x3 128 -> 8 as one 128 -> 16 GEMM padded to a
+        // 32-channel MFMA tile) + each head's flat BN + ReLU, as k_conv_heads computes them, from the raw x image: wave w takes cells
+        // [32 w, 32 w + 32) x the 32 channels.  72 MFMAs per wave with one MFMA per k-step, so the weight ring is three taps deep.
+        static_assert(!HEADS || (TM == 2 && WN == 2), "cell tile of wave w = lrow[w & 1]");
+        constexpr int HBSL = 32 * SLOTS, HRING = 24;
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.hw, 0, 9 * HBSL * 16, 0x00020000);
+        const int hvo = (lhi * 32 + l31) * 16;
+        auto ldh = [&](int tap, int ks) -> uint4 {
+            const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs, hvo, (tap * HBSL + ks * 2 * 32) * 16, 0);
+            return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+        };
+        uint4 hfr[HRING];
+#pragma unroll
+        for (int g = 0; g < HRING; ++g) hfr[g] = ldh(g / KS, g % KS);
+        const int hrow = wn ? lrow[1] : lrow[0];
+        const unsigned hmask = wn ? vmask[1] : vmask[0];
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+#pragma unroll 1
+        for (int t3 = 0; t3 < 3; ++t3) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int tap = t3 * 3 + tt, off = (t3 - 1) * a.W + (tt - 1);
+                const bool ok = (hmask >> tap) & 1u;
+                const int ar = hrow + off;
+                const int pbh = ok ? (ROWS + 1 + ar) * 256 + ((lhi ^ (ar & 15)) << 4) : ZROW * 256 + (lhi << 4);
+                uint4 hf[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) hf[ks] = *reinterpret_cast<const uint4*>(Ab + (pbh ^ (ks * 32)));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&hfr[tt * KS + ks]), *reinterpret_cast<bf16x8*>(&hf[ks]), hacc, 0, 0, 0);
+                    const int ntap = tap + 3 < 9 ? tap + 3 : tap;
+                    hfr[tt * KS + ks] = ldh(ntap, ks);
+                }
+            }
+        }
+        // lane: cell hrow, channels 8 j + 4 lhi + q: j = 0 policy head, j = 1 value head, j = 2, 3 padding
+        const long gr = m0 + hrow;
+        if (hrow < a.tile_rows && gr < a.M) {
+            const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = (int)((unsigned)gr - b * (unsigned)HW);
+            const int f = cell * 8 + 4 * lhi;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 bi = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhi);
+                const float4 sc = *reinterpret_cast<const float4*>((j ? a.v_fs : a.p_fs) + f);
+                const float4 sh = *reinterpret_cast<const float4*>((j ? a.v_ft : a.p_ft) + f);
+                float4 o;
+                o.x = fmaxf((hacc[4 * j + 0] + bi.x) * sc.x + sh.x, 0.0f); o.y = fmaxf((hacc[4 * j + 1] + bi.y) * sc.y + sh.y, 0.0f);
+                o.z = fmaxf((hacc[4 * j + 2] + bi.z) * sc.z + sh.z, 0.0f); o.w = fmaxf((hacc[4 * j + 3] + bi.w) * sc.w + sh.w, 0.0f);
+                *reinterpret_cast<float4*>((j ? a.v_feat : a.p_feat) + (size_t)b * (HW * 8) + f) = o;
+            }
+        }
+    } else {
     // ---- the tile's rows of x -> global, whole 256-byte rows
     uint4* out4 = reinterpret_cast<uint4*>(a.xout);
     for (int i = tid; i < a.tile_rows * SLOTS; i += TR_THREADS) {
         const int lr = i / SLOTS, sp = i % SLOTS;
         const long gr = m0 + lr;
         if (gr < a.M) out4[gr * SLOTS + sp] = Xs[lr * SLOTS + (sp ^ (lr & 15))];
+    }
     }
     TR_STAMP(63);
 }

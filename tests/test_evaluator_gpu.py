@@ -81,19 +81,22 @@ def test_rows_are_batch_independent():
 
 @pytest.mark.parametrize("blocks,n", [(1, 5), (6, 334), (3, 4096)])
 def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
-    """k_trunk (csrc/trunk.hpp: every residual block in one launch, activations resident in LDS) against one k_resblock3 launch
-    per block (GAZ_TRUNK=0): the same arithmetic in the same order => bit-exact outputs, ragged last tile included
-    (n not a multiple of the 3 boards a workgroup owns)."""
+    """k_trunk (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations resident
+    in LDS) against the blocks-only k_trunk behind k_stem_mfma / in front of k_conv_heads (GAZ_TRUNK_WHOLE=0) and against one
+    k_resblock3 launch per block (GAZ_TRUNK=0): the same arithmetic in the same order => bit-exact outputs, ragged last tile
+    included (n not a multiple of the 3 boards a workgroup owns)."""
     rng = np.random.default_rng(blocks + n)
     x = _random_states(n, rng) if n < 1000 else rng.integers(-1, 2, size=(n, 6, 7, 4)).astype(np.int8)
     outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GAZ_TRUNK", flag)
+    for trunk, whole in (("1", "1"), ("1", "0"), ("0", "0")):     # stem .. heads conv in one launch | blocks in one launch | per-block launches
+        monkeypatch.setenv("GAZ_TRUNK", trunk)
+        monkeypatch.setenv("GAZ_TRUNK_WHOLE", whole)
         net, eng = _mk(max(n, 64), blocks, True, seed=3)
         outs.append(eng.evaluate(x)[:2])
         eng.close()
     assert np.isfinite(outs[0][0]).all()
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
 
 
 def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
