@@ -338,28 +338,38 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+        // Image fragments: NB register buffers, k-step ks in afr[ks % NB], fetched NB - 1 k-steps ahead and across the tap boundary;
+        // __builtin_amdgcn_sched_barrier pins each k-step's reads, MFMAs and weight loads where they are written (left alone, the
+        // scheduler sinks every ds_read to just before its MFMA and all the ring's loads to the end of the tap: see trunk.hpp).
+        constexpr int NB = TM >= 4 ? 2 : 4, PD = NB - 1;
+        const char* Ab = reinterpret_cast<const char*>(As);
+        int pb[TM], pbn[TM];                        // byte address of k-slot 0 of this lane's image row: row * 256 | ((lhi ^ row & 15) << 4)
+        auto tap_rows = [&](int tap, int (&o)[TM]) {
+            const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bool ok = (vmask[tm] >> (conv * 9 + tap)) & 1u;
+                const int ar = ok ? lrow[tm] + h + off : ZROW;
+                o[tm] = ar * 256 + ((lhi ^ (ar & 15)) << 4);
+            }
+        };
+        uint4 afr[NB][TM];
+        tap_rows(0, pb);
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) afr[d][tm] = *reinterpret_cast<const uint4*>(Ab + (pb[tm] ^ (d * 32)));
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int sl = conv * 9 + tap;
             const int nsl = sl + 1 < 18 ? sl + 1 : sl;
-            const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
-            int abase[TM], axor[TM];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const bool ok = (vmask[tm] >> sl) & 1u;
-                const int ar = ok ? lrow[tm] + h + off : ZROW;
-                abase[tm] = ar * SLOTS; axor[tm] = ar & 15;
-            }
-            uint4 afr[2][TM];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) afr[0][tm] = As[abase[tm] + (lhi ^ axor[tm])];
+            tap_rows(tap < 8 ? tap + 1 : 8, pbn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int cur = ks & 1, nxt = cur ^ 1;
-                if (ks + 1 < KS) {
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) afr[nxt][tm] = As[abase[tm] + (((ks + 1) * 2 + lhi) ^ axor[tm])];
-                }
+                for (int tm = 0; tm < TM; ++tm)
+                    afr[(ks + PD) % NB][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + PD < KS ? pb[tm] : pbn[tm]) ^ (((ks + PD) % KS) * 32)));
                 bf16x8 bf[TN];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[cur][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&afr[ks % NB][tm]), bf[tn], acc[tm][tn], 0, 0, 0);
                 // refill this ring slot with k-step ks + RING (of this tap, or of the next one)
                 if (ks + RING < KS) {
 #pragma unroll
@@ -376,7 +386,10 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(nsl, ks + RING - KS, tn);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) pb[tm] = pbn[tm];
             RB_STAMP(3 + sl);
         }
         if (conv == 0) {

@@ -451,6 +451,7 @@ struct ResNetEvaluator : Evaluator {
     bool fused = true;
     int stamp_calls = 0, n_cus = 256;
     bf16_t* stem_frag = nullptr;
+    bool trunk_mix = true;                          // ... with the last partial round in cheaper 96-row tiles (k_trunk_mix); GAZ_TRUNK_MIX=0 -> one tile shape
     bool trunk_whole = true;                        // ... including the stem and the heads' first convolution; GAZ_TRUNK_WHOLE=0 -> k_stem_mfma / k_conv_heads
     bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
     bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;
@@ -576,11 +577,19 @@ struct ResNetEvaluator : Evaluator {
             r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
             r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
             r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"]; r.p_feat = pfeat; r.v_feat = vfeat;
-            const int nwg = (M + r.tile_rows - 1) / r.tile_rows;
+            int nwg = (M + r.tile_rows - 1) / r.tile_rows;
+            bool mix = false;
+            if (whole && trunk_mix && 96 / HW >= 1 && 96 / HW < 128 / HW) {    // whole rounds of 128-row tiles, the rest in 96-row tiles (k_trunk_mix)
+                const int slots = 2 * n_cus, bb = 128 / HW, sb = 96 / HW;
+                const int nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
+                const double cost_mix = nb / slots + 0.78 * ((ns + slots - 1) / slots), cost_big = (nwg + slots - 1) / slots;
+                if (cost_mix < cost_big) { mix = true; r.n_big = nb; r.small_rows = sb * HW; nwg = nb + ns; }
+            }
             static const char* stamp_path = getenv("GAZ_TRUNK_STAMPS");    // diagnostic: phase stamps of the third launch -> file
             const bool stamp = stamp_path && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * 128 * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * 128 * 8, s); }
-            if (whole) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            if (mix) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (whole) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             if (stamp) {
                 std::vector<unsigned long long> hst((size_t)nwg * 128);
@@ -965,6 +974,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->X2 = e->dalloc<bf16_t>(M * 128 + 1024); e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     e->trunk_whole = !(getenv("GAZ_TRUNK_WHOLE") && atoi(getenv("GAZ_TRUNK_WHOLE")) == 0);
+    e->trunk_mix = !(getenv("GAZ_TRUNK_MIX") && atoi(getenv("GAZ_TRUNK_MIX")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
@@ -975,6 +985,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

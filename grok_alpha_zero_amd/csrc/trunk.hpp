@@ -26,7 +26,8 @@ struct TrunkArgs {
     const bf16_t* w;                              // [nblocks][18 slices][8 k-steps][2][128][8], fragment order (arrange_conv_weights)
     const float* prm;                             // [nblocks][5][128]: bn1 scale, bn1 shift, conv1 scale, conv1 shift (bn2 folded), conv2 bias
     int M, H, W, nblocks;
-    int tile_rows;                                // k * H * W, k whole boards, <= 64 TM
+    int tile_rows;                                // k * H * W, k whole boards, <= the workgroup's MFMA rows
+    int n_big, small_rows;                        // k_trunk_mix: workgroups [0, n_big) take tile_rows each, the others small_rows
     unsigned long long* stamps;                   // diagnostic (GAZ_TRUNK_STAMPS, tools/trunk_stamps.py): [workgroup][128] or null
     // STEM: the stem convolution (k_stem_mfma's operands) computed straight into the images instead of reading xin
     const int8_t* planes; const uint4* stem_frag; const float* stem_shift;        // [M][4] int8; [6 k-steps][2][128] x 8 bf16 (hi | lo); [128]
@@ -54,8 +55,8 @@ constexpr size_t trunk_lds_bytes(int rows) { return (size_t)(2 * rows + 1) * 256
 // TM = 32-cell tiles per wave, WN = waves across the 128 channels (2: wave = 32 TM cells x 64 channels, two waves down the cells;
 // 4: wave = 32 TM cells x 32 channels, every wave all the cells of the tile — the workgroup then pulls each weight fragment from
 // L2 once instead of twice, for twice the LDS fragment reads per MFMA)
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS>
-__global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
+template <int TM, int WN, int RING, bool STEM, bool HEADS>
+__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
     constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
     extern __shared__ uint4 lds[];
@@ -68,7 +69,6 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lhi = lane >> 5;
     const int HW = a.H * a.W;
-    const long m0 = (long)blockIdx.x * a.tile_rows;
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
     const int last_slice = a.nblocks * 18 - 1;
     TR_STAMP(0);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
     for (int tm = 0; tm < TM; ++tm) {
         lrow[tm] = (wm * TM + tm) * 32 + l31;
         unsigned mm = 0;
-        if (lrow[tm] < a.tile_rows && m0 + lrow[tm] < a.M) {
+        if (lrow[tm] < tile_rows && m0 + lrow[tm] < a.M) {
             const int cell = lrow[tm] % HW, y = cell / a.W, x = cell % a.W;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         // ---- stem (Connect4/Build_Model.py:22-24: Conv3x3 4 -> 128, BN, GELU) as in k_stem_mfma: k = tap * 4 + plane padded to 48, the
         // fp32 weights (BN scale folded in) as bf16 hi + lo halves against the same exact int8 activations; x and block 0's operand
         // go straight into the images
-        static_assert(!STEM || TN == 2, "stem epilogue is written for the 2 x 2 wave tile");
         const int* in32 = reinterpret_cast<const int*>(a.planes);
         uint4 sw[6][TN];
 #pragma unroll
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const long gr = m0 + lrow[tm];
-            const bool rok = lrow[tm] < a.tile_rows && gr < a.M;
+            const bool rok = lrow[tm] < tile_rows && gr < a.M;
             uint4 cf[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
@@ -334,7 +333,6 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         // ---- first convolution of both heads (Connect4/Build_Model.py:41,62: two Conv3x3 128 -> 8 as one 128 -> 16 GEMM padded to a
         // 32-channel MFMA tile) + each head's flat BN + ReLU, as k_conv_heads computes them, from the raw x image: wave w takes cells
         // [32 w, 32 w + 32) x the 32 channels.  72 MFMAs per wave with one MFMA per k-step, so the weight ring is three taps deep.
-        static_assert(!HEADS || (TM == 2 && WN == 2), "cell tile of wave w = lrow[w & 1]");
         constexpr int HBSL = 32 * SLOTS, HRING = 24;
         const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.hw, 0, 9 * HBSL * 16, 0x00020000);
         const int hvo = (lhi * 32 + l31) * 16;
@@ -345,8 +343,11 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         uint4 hfr[HRING];
 #pragma unroll
         for (int g = 0; g < HRING; ++g) hfr[g] = ldh(g / KS, g % KS);
-        const int hrow = wn ? lrow[1] : lrow[0];
-        const unsigned hmask = wn ? vmask[1] : vmask[0];
+        const int htile = WN == 2 ? wn : wave;      // which of this wave's own cell tiles is cell tile `wave` of the workgroup
+        int hrow = lrow[0]; unsigned hmask = vmask[0];
+#pragma unroll
+        for (int tm = 1; tm < TM; ++tm) if (htile == tm) { hrow = lrow[tm]; hmask = vmask[tm]; }
+        if (htile < TM) {                           // wave-uniform (WN = 4, TM = 3: the fourth wave has no cell tile)
         f32x16 hacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
         }
         // lane: cell hrow, channels 8 j + 4 lhi + q: j = 0 policy head, j = 1 value head, j = 2, 3 padding
         const long gr = m0 + hrow;
-        if (hrow < a.tile_rows && gr < a.M) {
+        if (hrow < tile_rows && gr < a.M) {
             const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = (int)((unsigned)gr - b * (unsigned)HW);
             const int f = cell * 8 + 4 * lhi;
 #pragma unroll
@@ -385,16 +386,33 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
                 *reinterpret_cast<float4*>((j ? a.v_feat : a.p_feat) + (size_t)b * (HW * 8) + f) = o;
             }
         }
+        }
     } else {
     // ---- the tile's rows of x -> global, whole 256-byte rows
     uint4* out4 = reinterpret_cast<uint4*>(a.xout);
-    for (int i = tid; i < a.tile_rows * SLOTS; i += TR_THREADS) {
+    for (int i = tid; i < tile_rows * SLOTS; i += TR_THREADS) {
         const int lr = i / SLOTS, sp = i % SLOTS;
         const long gr = m0 + lr;
         if (gr < a.M) out4[gr * SLOTS + sp] = Xs[lr * SLOTS + (sp ^ (lr & 15))];
     }
     }
     TR_STAMP(63);
+}
+
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS>
+__global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
+    trunk_tile<TM, WN, RING, STEM, HEADS>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+}
+
+// Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
+// 2 x CUs tiles; 4096 Connect4 boards in 3-board tiles are 1366 tiles = 2.67 rounds, the third one two thirds full and as long as
+// the others.  Here the first n_big workgroups (whole rounds) take 3 boards in the 128-row shape and the rest 2 boards in a 96-row
+// shape (TM = 3, WN = 4: every wave all 96 cells x 32 channels) that issues three quarters of the MFMAs: 1024 + 512 tiles = three full
+// rounds, the last one cheaper.
+template <int RING, int OCC, bool STEM, bool HEADS>
+__global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk_mix(TrunkArgs a) {
+    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    else trunk_tile<3, 4, RING, STEM, HEADS>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows);
 }
 
 }  // namespace gaz

@@ -84,13 +84,16 @@ def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
     """k_trunk (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations resident
     in LDS) against the blocks-only k_trunk behind k_stem_mfma / in front of k_conv_heads (GAZ_TRUNK_WHOLE=0) and against one
     k_resblock3 launch per block (GAZ_TRUNK=0): the same arithmetic in the same order => bit-exact outputs, ragged last tile
-    included (n not a multiple of the 3 boards a workgroup owns)."""
+    included (n not a multiple of the 3 boards a workgroup owns); k_trunk_mix (3-board tiles for the whole rounds, 2-board tiles
+    in a 96-row shape for the rest; all 2-board tiles at the small sizes) against the single-shape launch."""
     rng = np.random.default_rng(blocks + n)
     x = _random_states(n, rng) if n < 1000 else rng.integers(-1, 2, size=(n, 6, 7, 4)).astype(np.int8)
     outs = []
-    for trunk, whole in (("1", "1"), ("1", "0"), ("0", "0")):     # stem .. heads conv in one launch | blocks in one launch | per-block launches
+    # stem .. heads conv in one launch, two tile shapes | one tile shape | blocks only in one launch | per-block launches
+    for trunk, whole, mix in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0")):
         monkeypatch.setenv("GAZ_TRUNK", trunk)
         monkeypatch.setenv("GAZ_TRUNK_WHOLE", whole)
+        monkeypatch.setenv("GAZ_TRUNK_MIX", mix)
         net, eng = _mk(max(n, 64), blocks, True, seed=3)
         outs.append(eng.evaluate(x)[:2])
         eng.close()
