@@ -147,10 +147,11 @@ def main():
             avg_ms = tm["ms_dominant"] / tm["n_dominant"]
             ach = kflops / (avg_ms * 1e-3) / 1e12
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")       # per-launch HBM bytes from the PMC passes (tools/pmc_traffic.py)
-            if args.config == "connect4" and G == 4096 and os.path.exists(tf):
+            # per-launch HBM bytes of the dominant kernel from the PMC passes (tools/pmc_traffic.py; measured on this workload only)
+            import glob
+            for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
                 tj = json.load(open(tf))
-                if tj.get("kernel_tag") and tj["kernel_tag"] in kname:
+                if args.config == "connect4" and G == 4096 and tj.get("kernel_tag") and kname.startswith(tj["kernel_tag"]):
                     traffic = tj.get("bytes_per_launch")
             roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
                         kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))

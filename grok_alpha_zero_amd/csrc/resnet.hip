@@ -661,7 +661,8 @@ struct ResNetEvaluator : Evaluator {
     const char* dominant_kernel(int n, double* flops) override {
         const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
         *flops = fused ? 2 * conv : conv;
-        if (fused && trunk) { *flops = 2 * conv * blocks; return "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"; }
+        if (fused && trunk) { *flops = 2 * conv * blocks; return trunk_whole ? "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"
+                               : "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"; }
         return fused ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                      : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
