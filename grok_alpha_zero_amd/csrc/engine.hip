@@ -182,7 +182,8 @@ template <class G> struct EngineT : gaz_engine {
     bool timing = false;
     std::vector<hipEvent_t> ev;      // every timing event (owned)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_eval;   // brackets around tree steps / evaluator passes
-    int64_t n_waves_total = 0;
+    int64_t n_waves_total = 0, n_waves_timed = 0;
+    static constexpr int TIMING_STRIDE = 8;
     std::vector<void*> allocs;
 
     template <class T> int dalloc(T** p, size_t n) {
@@ -342,12 +343,15 @@ template <class G> struct EngineT : gaz_engine {
     void launch_wave() { launch_wave(stream, 0, E.n_games); }
 
     int one_wave(bool with_eval) {
+        // timing brackets on every TIMING_STRIDE-th wave only: an event record is a barrier packet of its own (~5 us between two
+        // kernels; five of them per wave were 4 % of the wave they measured)
+        const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
         launch_wave();
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
-        if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); }
+        if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); n_waves_timed++; }
         if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
         n_waves_total++;
         return 0;
@@ -397,7 +401,7 @@ template <class G> struct EngineT : gaz_engine {
                 if (timing) { hipEventRecord(v1, stream); ev_eval.push_back({v0, v1}); }
                 hipEventRecord(ce[2 + half], stream);
             }
-            n_waves_total++;
+            n_waves_total++; if (timing) n_waves_timed++;
         }
         HIP_OK(hipGetLastError());
         return 0;                                   // `stream` ends with eval(B, n - 1): every tree step is ordered before it
@@ -554,7 +558,7 @@ template <class G> struct EngineT : gaz_engine {
     int timing_reset(int enable) override {
         HIP_OK(hipStreamSynchronize(stream));
         for (hipEvent_t e : ev) hipEventDestroy(e);
-        ev.clear(); ev_tree.clear(); ev_eval.clear(); n_waves_total = 0; timing = enable != 0;
+        ev.clear(); ev_tree.clear(); ev_eval.clear(); n_waves_total = 0; n_waves_timed = 0; timing = enable != 0;
         if (eval) eval->timing_reset();
         return 0;
     }
@@ -588,7 +592,7 @@ template <class G> struct EngineT : gaz_engine {
         if (ms_tree) *ms_tree = t; if (ms_eval) *ms_eval = e;
         double d = 0; int64_t nd = 0;
         if (eval) eval->timing_get(&d, &nd);
-        if (ms_dom) *ms_dom = d; if (n_dom) *n_dom = nd; if (n_waves) *n_waves = n_waves_total;
+        if (ms_dom) *ms_dom = d; if (n_dom) *n_dom = nd; if (n_waves) *n_waves = n_waves_timed;
         return 0;
     }
 };
