@@ -679,6 +679,7 @@ struct GenericEvaluator : Evaluator {
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
     std::vector<hipEvent_t> tev; int trunk_convs = 0;
     bool fused = true, block0_fused = false; int n_cus = 256, fused_blocks = 0;   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
+    bool trunk = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
     bf16_t* stem_frag = nullptr;
 
     ~GenericEvaluator() override { for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e); }
@@ -765,6 +766,17 @@ struct GenericEvaluator : Evaluator {
                  up("p.d1.w", HW * 8 * 128) && up("p.d1.bias", 128) && up("p.d2.w", 128 * 64) && up("p.d2.bias", 64) && up("p.d3.w", 64 * A) && up("p.d3.bias", A) &&
                  up("v.d1.w", HW * 4 * 128) && up("v.d1.bias", 128) && up("v.d2.w", 128 * 64) && up("v.d2.bias", 64) && up("v.d3.w", 64) && up("v.d3.bias", 1);
         }
+        if (ok && gomoku && blocks > 1 && F == 128) {     // k_trunk operands of blocks 1..: slices as one array, parameters as [block][5][128]
+            const size_t WB = 18 * (size_t)F * F; const int nb = blocks - 1;
+            trunk_w = dalloc<bf16_t>(nb * WB); trunk_prm = dalloc<float>((size_t)nb * TR_PRM);
+            ok = trunk_w && trunk_prm; if (!ok) lerr = "hipMalloc";
+            for (int i = 1; ok && i < blocks; ++i) {
+                const std::string b = "block" + std::to_string(i);
+                hipMemcpy(trunk_w + (i - 1) * WB, b16[b + ".conv1.w"], WB * 2, hipMemcpyDeviceToDevice);       // conv2 sits right behind conv1 (up_mfma_pair)
+                const char* names[5] = {".bn1.scale", ".bn1.shift", ".conv1.scale", ".conv1.shift", ".conv2.bias"};
+                for (int k = 0; k < 5; ++k) hipMemcpy(trunk_prm + ((size_t)(i - 1) * 5 + k) * 128, f32[b + names[k]], 128 * 4, hipMemcpyDeviceToDevice);
+            }
+        }
         hipStreamSynchronize(s);
         if (!ok) { *err = lerr; return 1; }
         loaded = true; return 0;
@@ -842,6 +854,13 @@ struct GenericEvaluator : Evaluator {
                 else if (plan.tm == 3) hipLaunchKernelGGL((k_block0<3, 8>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<3>(), s, r);
                 else hipLaunchKernelGGL((k_block0<4, 4>), dim3(nwg), dim3(RB3_THREADS), rb3_lds_bytes<4>(), s, r);
                 cur = X; fused_blocks++; block0_fused = true;
+                if (trunk && trunk_w && HW <= 256) {   // blocks 1.. in one launch: one board per workgroup, residual stream through L2 (trunk.hpp, RESG)
+                    TrunkArgs t; memset(&t, 0, sizeof(t));
+                    t.xin = X; t.xout = Hh; t.w = trunk_w; t.prm = trunk_prm; t.M = M; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
+                    hipLaunchKernelGGL((k_trunk<4, 2, 4, 2, false, false, true>), dim3(n), dim3(TR_THREADS), trunk_lds_bytes(256, true), s, t);
+                    cur = Hh; fused_blocks += blocks - 1;
+                    break;
+                }
                 continue;
             }
             if (fuse && !first) {                   // whole block in one kernel: raw x in, raw x out (pre-activation on load)
@@ -928,6 +947,7 @@ struct GenericEvaluator : Evaluator {
         if (!gomoku) { *flops = 0; return ""; }
         const bool fz = fused && blocks > 1;
         *flops = fz ? 2 * conv : conv;
+        if (fz && trunk && trunk_w) return "k_trunk<4,2,RESG> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)";
         return fz ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                   : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
@@ -941,6 +961,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     e->H = H; e->W = W; e->C = C; e->A = A; e->HW = H * W; e->blocks = cfg.net_blocks; e->F = gomoku ? 128 : 64; e->nmax = cfg.n_games;
     e->logits = cfg.policy_is_logits; e->gomoku = gomoku;
     e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
+    e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
@@ -952,6 +973,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     }
     hipFuncSetAttribute((const void*)(k_block0<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_head32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
+    hipFuncSetAttribute((const void*)(k_trunk<4, 2, 4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256, true));
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

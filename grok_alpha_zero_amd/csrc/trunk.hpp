@@ -50,19 +50,24 @@ __device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two
 // 3 + 6 b + {0 conv1 taps, 1 barrier, 2 h written + barrier, 3 conv2 taps, 4 barrier, 5 epilogue + barrier} for b < 10, 63 end
 #define TR_STAMP(i) do { if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 128 + (i)] = wall_clock64(); a.stamps[(size_t)blockIdx.x * 128 + 64 + (i)] = clock64(); } } while (0)
 constexpr int TR_THREADS = 256, TR_PRM = 5 * 128;
-constexpr size_t trunk_lds_bytes(int rows) { return (size_t)(2 * rows + 1) * 256 + 2 * TR_PRM * 4; }
+constexpr size_t trunk_lds_bytes(int rows, bool resg = false) { return (size_t)((resg ? 1 : 2) * rows + 1) * 256 + 2 * TR_PRM * 4; }
 
 // TM = 32-cell tiles per wave, WN = waves across the 128 channels (2: wave = 32 TM cells x 64 channels, two waves down the cells;
 // 4: wave = 32 TM cells x 32 channels, every wave all the cells of the tile — the workgroup then pulls each weight fragment from
 // L2 once instead of twice, for twice the LDS fragment reads per MFMA)
-template <int TM, int WN, int RING, bool STEM, bool HEADS>
+// RESG: no x image in LDS — the residual stream goes through global memory (xin for the first block, xout afterwards; each lane
+// re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
+// board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false>
 __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
     constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
     extern __shared__ uint4 lds[];
     uint4* As = lds;                              // operand image, rows [0, ROWS) + the zero row
-    uint4* Xs = lds + (ROWS + 1) * SLOTS;         // raw stream
-    float* Ps = reinterpret_cast<float*>(Xs + ROWS * SLOTS);      // [2][5][128]
+    uint4* Xs = lds + (ROWS + 1) * SLOTS;         // raw stream (not with RESG)
+    float* Ps = reinterpret_cast<float*>(Xs + (RESG ? 0 : ROWS * SLOTS));      // [2][5][128]
+    static_assert(!RESG || (!STEM && !HEADS), "the stem / heads phases work on the x image");
+    constexpr int NB = TM >= 4 ? 2 : 4, PD = NB - 1;   // operand-fragment buffers and prefetch distance in k-steps
     char* Ab = reinterpret_cast<char*>(As);
     char* Xb = reinterpret_cast<char*>(Xs);
 
@@ -80,7 +85,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
         long gr = m0 + lr;
         gr = gr >= a.M ? (long)a.M - 1 : gr;
-        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(Xs + base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)((RESG ? As : Xs) + base), 16, 0, 0);
     }
     }
     if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
@@ -194,7 +199,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ps1[j] = Ps[tch0 + j]; pt1[j] = Ps[128 + tch0 + j]; }
         for (int i = tid; i < n_slots; i += TR_THREADS) {
-            const uint4 v = Xs[i];
+            const uint4 v = RESG ? As[i] : Xs[i];
             unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -224,7 +229,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-            // Cell-operand fragments: four register buffers, k-step ks in afr[ks % 4], fetched THREE k-steps ahead and across the
+            // Cell-operand fragments: NB register buffers (four; two at TM = 4, where a k-step is 256 MFMA cycles), k-step ks in
+            // afr[ks % NB], fetched NB - 1 k-steps ahead and across the
             // tap boundary (the last three k-steps of a tap fetch the next tap's first three), so no MFMA waits on an LDS
             // round trip.  __builtin_amdgcn_sched_barrier pins each k-step's reads, MFMAs and weight loads where they are
             // written: left alone, the scheduler sinks every ds_read to just before its MFMA and the ring's loads to the end of
@@ -239,10 +245,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                     o[tm] = ar * 256 + ((lhi ^ (ar & 15)) << 4);
                 }
             };
-            uint4 afr[4][TM];
+            uint4 afr[NB][TM];
             tap_rows(0, pb);
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < PD; ++d)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) afr[d][tm] = *reinterpret_cast<const uint4*>(Ab + (pb[tm] ^ (d * 32)));
 #pragma unroll 1
@@ -255,7 +261,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
-                        afr[(ks + 3) % 4][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + 3 < KS ? pb[tm] : pbn[tm]) ^ (((ks + 3) % KS) * 32)));
+                        afr[(ks + PD) % NB][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + PD < KS ? pb[tm] : pbn[tm]) ^ (((ks + PD) % KS) * 32)));
                     bf16x8 bf[TN];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
@@ -263,7 +269,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)     // D[channel][cell]: weights are the A operand
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[ks % 4][tm]), acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[tn], *reinterpret_cast<bf16x8*>(&afr[ks % NB][tm]), acc[tm][tn], 0, 0, 0);
                     if (ks + RING < KS) {
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn) bfr[ks % RING][tn] = ldb(sl, ks + RING, tn);
@@ -299,24 +305,42 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 if (blk < 10) TR_STAMP(5 + 6 * blk);
             }
         }
+        // RESG: the residual groups of the first cell tile are on their way while the barrier waits
+        const bf16_t* rsrc = blk == 0 ? a.xin : a.xout;
+        uint2 rres[TN * 4];                         // one cell tile's groups at a time (a second buffer spills at TM = 4)
+        auto res_load = [&](int tm, uint2 (&o)[TN * 4]) {
+            const long gr = m0 + lrow[tm];
+            const bool rok = lrow[tm] < tile_rows && gr < a.M;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c0 = ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi;
+                    o[tn * 4 + j] = rok ? *reinterpret_cast<const uint2*>(rsrc + (size_t)gr * BN + c0) : make_uint2(0u, 0u);
+                }
+        };
+        if (RESG) res_load(0, rres);
         __syncthreads();                            // every wave is done with the h image
         if (blk < 10) TR_STAMP(7 + 6 * blk);
         // ---- x = bf16(acc + bias + x) in place; the next block's operand relu(x * s1' + t1') over the operand image
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+            const long grow = m0 + lrow[tm];
+            const bool rowok = lrow[tm] < tile_rows && grow < a.M;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c0 = ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi, o = img_off(tm, tn, j);
                     const float4 b = *reinterpret_cast<const float4*>(&P[4 * 128 + c0]);
-                    const uint2 xo = *reinterpret_cast<const uint2*>(Xb + o);
+                    const uint2 xo = RESG ? rres[tn * 4 + j] : *reinterpret_cast<const uint2*>(Xb + o);
                     const float v0 = (acc[tm][tn][4 * j + 0] + b.x) + __uint_as_float(xo.x << 16);
                     const float v1 = (acc[tm][tn][4 * j + 1] + b.y) + __uint_as_float(xo.x & 0xFFFF0000u);
                     const float v2 = (acc[tm][tn][4 * j + 2] + b.z) + __uint_as_float(xo.y << 16);
                     const float v3 = (acc[tm][tn][4 * j + 3] + b.w) + __uint_as_float(xo.y & 0xFFFF0000u);
                     const uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
-                    *reinterpret_cast<uint2*>(Xb + o) = xn;
+                    if (!RESG) *reinterpret_cast<uint2*>(Xb + o) = xn;
+                    else if (rowok) *reinterpret_cast<uint2*>(a.xout + (size_t)grow * BN + c0) = xn;
                     if (more) {
                         const float4 s = *reinterpret_cast<const float4*>(&Pn[c0]);
                         const float4 t = *reinterpret_cast<const float4*>(&Pn[128 + c0]);
@@ -325,6 +349,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                         *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
                     }
                 }
+            if (RESG && tm + 1 < TM) res_load(tm + 1, rres);
+        }
         __syncthreads();
         if (blk < 10) TR_STAMP(8 + 6 * blk);
     }
@@ -387,7 +413,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             }
         }
         }
-    } else {
+    } else if (!RESG) {
     // ---- the tile's rows of x -> global, whole 256-byte rows
     uint4* out4 = reinterpret_cast<uint4*>(a.xout);
     for (int i = tid; i < tile_rows * SLOTS; i += TR_THREADS) {
@@ -399,9 +425,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS>
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of

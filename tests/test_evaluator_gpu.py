@@ -102,6 +102,28 @@ def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
         assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
 
 
+@pytest.mark.parametrize("blocks,n", [(2, 3), (4, 37), (10, 300)])
+def test_gomoku_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
+    """Gomoku: k_block0 + ONE k_trunk launch for blocks 1.. (one board per workgroup, residual stream through L2: trunk.hpp RESG)
+    against k_block0 + one k_resblock3 launch per block (GAZ_TRUNK=0): bit-exact."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    rng = np.random.default_rng(blocks + n)
+    net = NETS["Gomoku"](blocks).eval()
+    net.randomize_bn()
+    x = rng.integers(-1, 2, size=(n, 15, 15, 2)).astype(np.int8)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GAZ_TRUNK", flag)
+        eng = SelfPlayEngine("Gomoku", max(n, 8), 50, 150, 2, 1, 1.25, 1.0, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks, net_filters=128,
+                             ring_capacity=0)
+        eng.load_weights(net.export_engine_weights())
+        outs.append(eng.evaluate(x)[:2])
+        eng.close()
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
     """End-to-end: HIP search + HIP network vs the CPU oracle whose session.run is served by the SAME HIP network
     (evaluate() on one row) — visit counts bit-exact, so tree kernels and evaluator compose correctly."""
