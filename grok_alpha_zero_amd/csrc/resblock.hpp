@@ -370,6 +370,7 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_resblock3(ResBlockArgs a) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
                     afr[(ks + PD) % NB][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + PD < KS ? pb[tm] : pbn[tm]) ^ (((ks + PD) % KS) * 32)));
+                __builtin_amdgcn_sched_barrier(0);          // reads first: moved behind the MFMAs they lose a k-step of their lead
                 bf16x8 bf[TN];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);

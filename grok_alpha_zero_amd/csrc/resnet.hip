@@ -451,6 +451,7 @@ struct ResNetEvaluator : Evaluator {
     bool fused = true;
     int stamp_calls = 0, n_cus = 256;
     bf16_t* stem_frag = nullptr;
+    bool trunk_m16 = true;                          // ... on v_mfma_f32_16x16x32_bf16 (higher clock held); GAZ_TRUNK_M16=0 -> 32x32x16 (bit-identical to k_resblock3)
     bool trunk_mix = true;                          // ... with the last partial round in cheaper 96-row tiles (k_trunk_mix); GAZ_TRUNK_MIX=0 -> one tile shape
     bool trunk_whole = true;                        // ... including the stem and the heads' first convolution; GAZ_TRUNK_WHOLE=0 -> k_stem_mfma / k_conv_heads
     bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
@@ -588,7 +589,9 @@ struct ResNetEvaluator : Evaluator {
             static const char* stamp_path = getenv("GAZ_TRUNK_STAMPS");    // diagnostic: phase stamps of the third launch -> file
             const bool stamp = stamp_path && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * 128 * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * 128 * 8, s); }
-            if (mix) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            if (mix && trunk_m16) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (whole && trunk_m16) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true, false, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (mix) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else if (whole) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             if (stamp) {
@@ -998,6 +1001,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     e->trunk_whole = !(getenv("GAZ_TRUNK_WHOLE") && atoi(getenv("GAZ_TRUNK_WHOLE")) == 0);
     e->trunk_mix = !(getenv("GAZ_TRUNK_MIX") && atoi(getenv("GAZ_TRUNK_MIX")) == 0);
+    e->trunk_m16 = !(getenv("GAZ_TRUNK_M16") && atoi(getenv("GAZ_TRUNK_M16")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     e->X = e->dalloc<bf16_t>(M * 128 + 1024); e->Aa = e->dalloc<bf16_t>(M * 128 + 1024); e->Hh = e->dalloc<bf16_t>(M * 128 + 1024);
     e->pfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8); e->vfeat = e->dalloc<float>((size_t)cfg.n_games * e->HW * 8);
@@ -1009,6 +1013,8 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)k_conv_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -58,7 +58,7 @@ constexpr size_t trunk_lds_bytes(int rows, bool resg = false) { return (size_t)(
 // RESG: no x image in LDS — the residual stream goes through global memory (xin for the first block, xout afterwards; each lane
 // re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
-template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false>
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false>
 __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
     constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
@@ -104,6 +104,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
     };
     uint4 bfr[RING][TN];
+    if (!M16)
 #pragma unroll
     for (int g = 0; g < RING; ++g)
 #pragma unroll
@@ -214,6 +215,149 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     __syncthreads();
     TR_STAMP(2);
 
+    if constexpr (M16) {
+    // ---- the blocks on v_mfma_f32_16x16x32_bf16.  Same FLOPs, same operand bytes and the same cycles per FLOP as 32x32x16, but the chip
+    // holds a higher clock on this shape (MI355X_MICROARCH.md 'DVFS give-back' item 7): measured here on a timing build with identical
+    // operand traffic, 1.70 -> 1.95 GHz in the kernel and -10 % kernel time at +5.6 % cycles.  Wave tile = NC 16-cell tiles x NCH
+    // 16-channel tiles; lane (l15, lq): operand row / column l15, k-group lq of the 32-wide k-step; D: cell l15, channels 4 lq ..+3, so
+    // the images still take 8-byte groups.  One accumulation order per output element whatever the tile shape.
+    static_assert(!M16 || !RESG, "16x16x32 path keeps x in LDS");
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int NC = 2 * TM, NCH = 2 * TN, KS32 = 4;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int bvo16 = (lq * BN + wn * (32 * TN) + l15) * 16;
+    auto ldw = [&](int slice, int ks32, int ct) -> uint4 {
+        const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo16, ((slice * BSL) + ks32 * 4 * BN + ct * 16) * 16, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    uint4 wfr[KS32][NCH];                           // weight ring: one tap (four k-steps) ahead
+#pragma unroll
+    for (int g = 0; g < KS32; ++g)
+#pragma unroll
+        for (int ct = 0; ct < NCH; ++ct) wfr[g][ct] = ldw(0, g, ct);
+    int crow[NC]; unsigned cmask[NC];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+        crow[t] = wm * TM * 32 + t * 16 + l15;
+        unsigned mm = 0;
+        if (crow[t] < tile_rows && m0 + crow[t] < a.M) {
+            const int cell = crow[t] % HW, y = cell / a.W, x = cell % a.W;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int dy = q / 3 - 1, dx = q % 3 - 1;
+                mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << q;
+            }
+        }
+        cmask[t] = mm;
+    }
+    auto off16 = [&](int ct, int t) -> int {        // this lane's 8-byte group (channels 16 ct + 4 lq ..+3 of the wave's slab) of cell crow[t]
+        const int row = crow[t], cslot = wn * TN * 4 + ct * 2 + (lq >> 1);
+        return row * 256 + ((cslot ^ (row & 15)) << 4) + (lq & 1) * 8;
+    };
+    f32x4 acc16[NCH][NC];
+#pragma unroll 1
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const float* P = Ps + (blk & 1) * TR_PRM;
+        const float* Pn = Ps + ((blk + 1) & 1) * TR_PRM;
+        const bool more = blk + 1 < a.nblocks;
+        float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (more && tid < TR_PRM / 4) pnext = prm4[(blk + 1) * (TR_PRM / 4) + tid];
+#pragma unroll
+        for (int conv = 0; conv < 2; ++conv) {
+#pragma unroll
+            for (int ct = 0; ct < NCH; ++ct)
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc16[ct][t][r] = 0.0f;
+            int pb[NC], pbn[NC];                    // byte address of k-group lq of k-step 0 of this lane's operand row
+            auto tap_rows = [&](int tap, int (&o)[NC]) {
+                const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const bool ok = (cmask[t] >> tap) & 1u;
+                    const int ar = ok ? crow[t] + off : ZROW;
+                    o[t] = ar * 256 + ((lq ^ (ar & 15)) << 4);
+                }
+            };
+            uint4 cfr[2][NC];                       // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
+            tap_rows(0, pb);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) cfr[0][t] = *reinterpret_cast<const uint4*>(Ab + pb[t]);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sl = blk * 18 + conv * 9 + tap;
+                const int nsl = sl < last_slice ? sl + 1 : sl;
+                tap_rows(tap < 8 ? tap + 1 : 8, pbn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS32; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        cfr[(ks + 1) & 1][t] = *reinterpret_cast<const uint4*>(Ab + ((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 6)));
+                    __builtin_amdgcn_sched_barrier(0);      // reads first: behind the MFMAs they would land in the registers those just used, zero k-steps ahead
+#pragma unroll
+                    for (int ct = 0; ct < NCH; ++ct)
+#pragma unroll
+                        for (int t = 0; t < NC; ++t)
+                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);    // the next slice's k-step ks; the very last slice re-reads itself
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < NC; ++t) pb[t] = pbn[t];
+            }
+            if (blk < 10) TR_STAMP(3 + 6 * blk + 3 * conv);
+            if (conv == 0) {
+                if (more && tid < TR_PRM / 4) Ps4[((blk + 1) & 1) * (TR_PRM / 4) + tid] = pnext;
+                __syncthreads();                    // every wave is done with the operand image
+                if (blk < 10) TR_STAMP(4 + 6 * blk);
+#pragma unroll
+                for (int ct = 0; ct < NCH; ++ct) {
+                    const int c0 = wn * TN * 32 + ct * 16 + 4 * lq;
+                    const float4 s = *reinterpret_cast<const float4*>(&P[2 * 128 + c0]);
+                    const float4 t4 = *reinterpret_cast<const float4*>(&P[3 * 128 + c0]);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) {
+                        const float v0 = fmaxf(acc16[ct][t][0] * s.x + t4.x, 0.0f), v1 = fmaxf(acc16[ct][t][1] * s.y + t4.y, 0.0f);
+                        const float v2 = fmaxf(acc16[ct][t][2] * s.z + t4.z, 0.0f), v3 = fmaxf(acc16[ct][t][3] * s.w + t4.w, 0.0f);
+                        *reinterpret_cast<uint2*>(Ab + off16(ct, t)) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                    }
+                }
+                __syncthreads();
+                if (blk < 10) TR_STAMP(5 + 6 * blk);
+            }
+        }
+        __syncthreads();                            // every wave is done with the h image
+        if (blk < 10) TR_STAMP(7 + 6 * blk);
+#pragma unroll
+        for (int ct = 0; ct < NCH; ++ct) {
+            const int c0 = wn * TN * 32 + ct * 16 + 4 * lq;
+            const float4 b = *reinterpret_cast<const float4*>(&P[4 * 128 + c0]);
+            const float4 s = *reinterpret_cast<const float4*>(&Pn[c0]);
+            const float4 t4 = *reinterpret_cast<const float4*>(&Pn[128 + c0]);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const int o = off16(ct, t);
+                const uint2 xo = *reinterpret_cast<const uint2*>(Xb + o);
+                const float v0 = (acc16[ct][t][0] + b.x) + __uint_as_float(xo.x << 16);
+                const float v1 = (acc16[ct][t][1] + b.y) + __uint_as_float(xo.x & 0xFFFF0000u);
+                const float v2 = (acc16[ct][t][2] + b.z) + __uint_as_float(xo.y << 16);
+                const float v3 = (acc16[ct][t][3] + b.w) + __uint_as_float(xo.y & 0xFFFF0000u);
+                const uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                *reinterpret_cast<uint2*>(Xb + o) = xn;
+                if (more) {
+                    const float a0 = fmaxf(__uint_as_float(xn.x << 16) * s.x + t4.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * s.y + t4.y, 0.0f);
+                    const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t4.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t4.w, 0.0f);
+                    *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+                }
+            }
+        }
+        __syncthreads();
+        if (blk < 10) TR_STAMP(8 + 6 * blk);
+    }
+    } else {
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -262,6 +406,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
                         afr[(ks + PD) % NB][tm] = *reinterpret_cast<const uint4*>(Ab + ((ks + PD < KS ? pb[tm] : pbn[tm]) ^ (((ks + PD) % KS) * 32)));
+                    __builtin_amdgcn_sched_barrier(0);      // reads first (see the 16x16x32 loop)
                     bf16x8 bf[TN];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<bf16x8*>(&bfr[ks % RING][tn]);
@@ -354,6 +499,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         __syncthreads();
         if (blk < 10) TR_STAMP(8 + 6 * blk);
     }
+    }
 
     if (HEADS) {
         // ---- first convolution of both heads (Connect4/Build_Model.py:41,62: two Conv3x3 128 -> 8 as one 128 -> 16 GEMM padded to a
@@ -425,9 +571,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false>
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
@@ -435,10 +581,10 @@ __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
 // the others.  Here the first n_big workgroups (whole rounds) take 3 boards in the 128-row shape and the rest 2 boards in a 96-row
 // shape (TM = 3, WN = 4: every wave all 96 cells x 32 channels) that issues three quarters of the MFMAs: 1024 + 512 tiles = three full
 // rounds, the last one cheaper.
-template <int RING, int OCC, bool STEM, bool HEADS>
+template <int RING, int OCC, bool STEM, bool HEADS, bool M16 = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk_mix(TrunkArgs a) {
-    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
-    else trunk_tile<3, 4, RING, STEM, HEADS>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows);
+    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows);
 }
 
 }  // namespace gaz

@@ -81,25 +81,32 @@ def test_rows_are_batch_independent():
 
 @pytest.mark.parametrize("blocks,n", [(1, 5), (6, 334), (3, 4096)])
 def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
-    """k_trunk (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations resident
-    in LDS) against the blocks-only k_trunk behind k_stem_mfma / in front of k_conv_heads (GAZ_TRUNK_WHOLE=0) and against one
-    k_resblock3 launch per block (GAZ_TRUNK=0): the same arithmetic in the same order => bit-exact outputs, ragged last tile
-    included (n not a multiple of the 3 boards a workgroup owns); k_trunk_mix (3-board tiles for the whole rounds, 2-board tiles
-    in a 96-row shape for the rest; all 2-board tiles at the small sizes) against the single-shape launch."""
+    """k_trunk / k_trunk_mix (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations
+    resident in LDS).  On v_mfma_f32_32x32x16_bf16 (GAZ_TRUNK_M16=0) it is the arithmetic of the per-block kernels in the same order:
+    mixed tile shapes | one tile shape | blocks only (behind k_stem_mfma, in front of k_conv_heads) | one k_resblock3 launch per block
+    are bit-exact against each other, ragged last tiles included (n not a multiple of the 3 or 2 boards a workgroup owns).  The default
+    build of the blocks (v_mfma_f32_16x16x32_bf16: another accumulation order inside the MFMA) is bit-exact between its own two launch
+    configurations — a board's outputs must not depend on the tile shape it lands in — and within bf16 tolerance of the 32x32x16 one."""
     rng = np.random.default_rng(blocks + n)
     x = _random_states(n, rng) if n < 1000 else rng.integers(-1, 2, size=(n, 6, 7, 4)).astype(np.int8)
-    outs = []
-    # stem .. heads conv in one launch, two tile shapes | one tile shape | blocks only in one launch | per-block launches
-    for trunk, whole, mix in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "0"), ("0", "0", "0")):
-        monkeypatch.setenv("GAZ_TRUNK", trunk)
-        monkeypatch.setenv("GAZ_TRUNK_WHOLE", whole)
-        monkeypatch.setenv("GAZ_TRUNK_MIX", mix)
+
+    def run(trunk, whole, mix, m16):
+        for k, v in (("GAZ_TRUNK", trunk), ("GAZ_TRUNK_WHOLE", whole), ("GAZ_TRUNK_MIX", mix), ("GAZ_TRUNK_M16", m16)):
+            monkeypatch.setenv(k, v)
         net, eng = _mk(max(n, 64), blocks, True, seed=3)
-        outs.append(eng.evaluate(x)[:2])
+        out = eng.evaluate(x)[:2]
         eng.close()
-    assert np.isfinite(outs[0][0]).all()
-    for o in outs[1:]:
-        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
+        return out
+    ref32 = run("1", "1", "1", "0")
+    assert np.isfinite(ref32[0]).all()
+    for cfg in (("1", "1", "0", "0"), ("1", "0", "0", "0"), ("0", "0", "0", "0")):
+        o = run(*cfg)
+        assert np.array_equal(ref32[0], o[0]) and np.array_equal(ref32[1], o[1]), cfg
+    d16 = run("1", "1", "1", "1")
+    o = run("1", "1", "0", "1")
+    assert np.array_equal(d16[0], o[0]) and np.array_equal(d16[1], o[1])
+    dp = np.abs(d16[0] - ref32[0]); dv = np.abs(d16[1] - ref32[1])
+    assert dp.max() <= 6e-2 and dp.mean() <= 3e-3 and dv.max() <= 0.15 and dv.mean() <= 1e-2, (dp.max(), dp.mean(), dv.max(), dv.mean())
 
 
 @pytest.mark.parametrize("blocks,n", [(2, 3), (4, 37), (10, 300)])
