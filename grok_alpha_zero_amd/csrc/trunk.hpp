@@ -255,6 +255,12 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         return row * 256 + ((cslot ^ (row & 15)) << 4) + (lq & 1) * 8;
     };
     f32x4 acc16[NCH][NC];
+    // fragment reads by absolute LDS address: one v_xor per read (base ^ k-step bits; the image starts on a 256-byte boundary), where
+    // pointer arithmetic on the shared array costs an extra add of its link-time base per read — issue slots the MFMAs' shadows lack
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4_t* lds_u4_t;
+    const unsigned ldsb = (unsigned)(size_t)(lds_ptr_t)As;
+    if (ldsb & 255u) __builtin_trap();
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -277,13 +283,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 for (int t = 0; t < NC; ++t) {
                     const bool ok = (cmask[t] >> tap) & 1u;
                     const int ar = ok ? crow[t] + off : ZROW;
-                    o[t] = ar * 256 + ((lq ^ (ar & 15)) << 4);
+                    o[t] = (int)ldsb + ar * 256 + ((lq ^ (ar & 15)) << 4);
                 }
             };
-            uint4 cfr[2][NC];                       // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
+            u32x4_t cfr[2][NC];                     // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
             tap_rows(0, pb);
 #pragma unroll
-            for (int t = 0; t < NC; ++t) cfr[0][t] = *reinterpret_cast<const uint4*>(Ab + pb[t]);
+            for (int t = 0; t < NC; ++t) cfr[0][t] = *(lds_u4_t)(unsigned)pb[t];
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int sl = blk * 18 + conv * 9 + tap;
@@ -293,11 +299,20 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
                 for (int ks = 0; ks < KS32; ++ks) {
 #pragma unroll
-                    for (int t = 0; t < NC; ++t)
-                        cfr[(ks + 1) & 1][t] = *reinterpret_cast<const uint4*>(Ab + ((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 6)));
-                    __builtin_amdgcn_sched_barrier(0);      // reads first: behind the MFMAs they would land in the registers those just used, zero k-steps ahead
+                    for (int ct = 0; ct < NCH / 2; ++ct)
 #pragma unroll
-                    for (int ct = 0; ct < NCH; ++ct)
+                        for (int t = 0; t < NC; ++t)
+                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+                    // the next k-step's reads in the middle of this one's MFMAs: this k-step's fragments are still live, so they cannot
+                    // be allocated over them (behind the last MFMA the scheduler does exactly that: prefetch distance zero), and they
+                    // issue in the shadow of the MFMAs above
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        cfr[(ks + 1) & 1][t] = *(lds_u4_t)(unsigned)((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 6));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = NCH / 2; ct < NCH; ++ct)
 #pragma unroll
                         for (int t = 0; t < NC; ++t)
                             acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
