@@ -682,7 +682,7 @@ struct GenericEvaluator : Evaluator {
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
     std::vector<hipEvent_t> tev; int trunk_convs = 0;
     bool fused = true, block0_fused = false; int n_cus = 256, fused_blocks = 0;   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
-    bool trunk = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
+    bool trunk = true, trunk_m16 = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
     bf16_t* stem_frag = nullptr;
 
     ~GenericEvaluator() override { for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e); }
@@ -860,7 +860,10 @@ struct GenericEvaluator : Evaluator {
                 if (trunk && trunk_w && HW <= 256) {   // blocks 1.. in one launch: one board per workgroup, residual stream through L2 (trunk.hpp, RESG)
                     TrunkArgs t; memset(&t, 0, sizeof(t));
                     t.xin = X; t.xout = Hh; t.w = trunk_w; t.prm = trunk_prm; t.M = M; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
-                    hipLaunchKernelGGL((k_trunk<4, 2, 4, 2, false, false, true>), dim3(n), dim3(TR_THREADS), trunk_lds_bytes(256, true), s, t);
+                    // default: 8 waves (WM = 4 x WN = 2, the Connect4 wave tile on 16x16x32), one workgroup per CU, x and operand images in
+                    // LDS; GAZ_TRUNK_M16=0: 4 waves of 128 cells x 64 channels on 32x32x16, two workgroups per CU, residual stream through L2
+                    if (trunk_m16) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8>), dim3(n), dim3(512), trunk_lds_bytes(256), s, t);
+                    else hipLaunchKernelGGL((k_trunk<4, 2, 4, 2, false, false, true>), dim3(n), dim3(TR_THREADS), trunk_lds_bytes(256, true), s, t);
                     cur = Hh; fused_blocks += blocks - 1;
                     break;
                 }
@@ -965,6 +968,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     e->logits = cfg.policy_is_logits; e->gomoku = gomoku;
     e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
+    e->trunk_m16 = !(getenv("GAZ_TRUNK_M16") && atoi(getenv("GAZ_TRUNK_M16")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
@@ -977,6 +981,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     hipFuncSetAttribute((const void*)(k_block0<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)k_conv_head32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_trunk<4, 2, 4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256, true));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256));
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

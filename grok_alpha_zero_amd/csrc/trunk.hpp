@@ -58,9 +58,11 @@ constexpr size_t trunk_lds_bytes(int rows, bool resg = false) { return (size_t)(
 // RESG: no x image in LDS — the residual stream goes through global memory (xin for the first block, xout afterwards; each lane
 // re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
-template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false>
+// NW = waves per workgroup (4; 8 for the 256-row Gomoku tile: WM = 4 waves down the cells, one workgroup per CU with both images in LDS).
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4>
 __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
-    constexpr int BN = 128, SLOTS = 16, WM = 4 / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS;
+    constexpr int BN = 128, SLOTS = 16, WM = NW / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS, THREADS = 64 * NW;
+    static_assert(NW == 4 || (!STEM && !HEADS), "stem / heads phases assume four waves");
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
     extern __shared__ uint4 lds[];
     uint4* As = lds;                              // operand image, rows [0, ROWS) + the zero row
@@ -81,7 +83,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     constexpr int n_slots = ROWS * SLOTS;
     if (!STEM) {
     // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
-    for (int base = wave * 64; base < n_slots; base += TR_THREADS) {
+    for (int base = wave * 64; base < n_slots; base += THREADS) {
         const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
         long gr = m0 + lr;
         gr = gr >= a.M ? (long)a.M - 1 : gr;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         float ps1[8], pt1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ps1[j] = Ps[tch0 + j]; pt1[j] = Ps[128 + tch0 + j]; }
-        for (int i = tid; i < n_slots; i += TR_THREADS) {
+        for (int i = tid; i < n_slots; i += THREADS) {
             const uint4 v = RESG ? As[i] : Xs[i];
             unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -577,7 +579,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     } else if (!RESG) {
     // ---- the tile's rows of x -> global, whole 256-byte rows
     uint4* out4 = reinterpret_cast<uint4*>(a.xout);
-    for (int i = tid; i < tile_rows * SLOTS; i += TR_THREADS) {
+    for (int i = tid; i < tile_rows * SLOTS; i += THREADS) {
         const int lr = i / SLOTS, sp = i % SLOTS;
         const long gr = m0 + lr;
         if (gr < a.M) out4[gr * SLOTS + sp] = Xs[lr * SLOTS + (sp ^ (lr & 15))];
@@ -586,9 +588,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false>
-__global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
