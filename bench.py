@@ -25,7 +25,7 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)     # 8 x 400 waves = ~20 plies of every game at 200 sims/move (measure >= 20 plies per game)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="connect4", choices=["connect4", "gomoku", "gumbel"],
                     help="connect4 = BASELINE configs[1] (headline); gomoku = configs[3]; gumbel = configs[4]")
