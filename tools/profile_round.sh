@@ -21,3 +21,8 @@ echo "== rocprofv3 --pmc WRITE_SIZE"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_w.log 2>&1 || exit 1
 find $out -name "*.csv" | head -20
 echo done
+echo "== rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (MFMA utilisation)"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_m -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_m.log 2>&1 || exit 1
+echo "== rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out/pmc_l -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_l.log 2>&1 || exit 1
+echo done2
