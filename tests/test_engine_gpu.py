@@ -208,15 +208,18 @@ def test_hip_opening_actions_match_reference(name):
     eng.close()
 
 
-def test_hip_evaluation_cache_gives_identical_games():
+@pytest.mark.parametrize("G,ring", [(512, 8192), (3200, 16384)])
+def test_hip_evaluation_cache_gives_identical_games(G, ring):
     """eval_cache_log2 (on-device evaluation cache): with the HIP ResNet evaluator the finished games are bit-identical with the
-    cache on and off (rows of a batch are independent, so cached outputs equal fresh ones), and a good share of requests hit."""
+    cache on and off (rows of a batch are independent, so cached outputs equal fresh ones), and a good share of requests hit.
+    3200 games: the evaluator launch then mixes both tile shapes of k_trunk_mix (1024 three-board + 64 two-board workgroups), and a
+    position cached out of one shape is later compared with fresh outputs out of the other."""
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
     from grok_alpha_zero_amd.net import Connect4Net
     w = Connect4Net(2, seed=3).eval().export_engine_weights()
     got = []
     for log2 in (0, 16):
-        eng = SelfPlayEngine("Connect4", 512, 32, 16, 4, 3, 2.5, 0.5, seed=21, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192,
+        eng = SelfPlayEngine("Connect4", G, 32, 16, 4, 3, 2.5, 0.5, seed=21, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=ring,
                              eval_cache_log2=log2)
         eng.load_weights(w)
         eng.run_waves(900); eng.synchronize()
@@ -226,7 +229,7 @@ def test_hip_evaluation_cache_gives_identical_games():
     (ra, h0, e0), (rb, h1, e1) = got
     assert h0 == 0 and h1 > 0.1 * e1
     common = sorted(set(ra) & set(rb))
-    assert len(common) >= 512 and len(rb) >= len(ra)
+    assert len(common) >= G and len(rb) >= len(ra)
     for k in common:
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(ra[k][f]), np.asarray(rb[k][f]), err_msg=f"{k} {f}")
