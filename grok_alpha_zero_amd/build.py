@@ -1,29 +1,50 @@
-"""Builds libgaz_engine.so (HIP, gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+"""Builds libgaz_engine.so (HIP, gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
+One object per translation unit (compiled in parallel, rebuilt only when its sources changed), then one link."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(_PKG, "libgaz_engine.so")
-SOURCES = ["engine.hip", "resnet.hip"]
+HEADER = os.path.join(os.path.dirname(_PKG), "include", "gaz_engine.h")
+# translation unit -> the headers it includes (rebuild trigger)
+UNITS = {
+    "engine.hip": ["rt.hpp", "wave.hpp", "det.hpp", "games.hpp", "tree.hpp", "puct_core.hpp", "gumbel_core.hpp", "evaluator.hpp"],
+    "resnet.hip": ["rt.hpp", "wave.hpp", "evaluator.hpp", "netops.hpp", "conv3x3.hpp", "resblock.hpp", "trunk.hpp"],
+}
 # -ffp-contract=off: the injected-noise samplers and PUCT scores must not be FMA-contracted (bit parity)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value",
+         "-Wno-int-to-pointer-cast"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(_PKG), "include", "gaz_engine.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_engine(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    known = {h for hs in UNITS.values() for h in hs} | set(UNITS)
+    extra = [f for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip")) and f not in known]     # unlisted source: rebuild everything
+    jobs = []
+    for src, hdrs in UNITS.items():
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        deps = [os.path.join(CSRC, src), HEADER, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in hdrs + extra]
+        if force or _newer(obj, deps):
+            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    with ThreadPoolExecutor(max_workers=max(len(jobs), 1)) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in UNITS]
+    if jobs or _newer(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB

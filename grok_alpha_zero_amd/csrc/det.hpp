@@ -100,6 +100,14 @@ GAZ_DEV double dexp(double x) {
     return y * bits2d((uint64_t)(1023 - 1000) << 52);
 }
 
+// x ** y for x >= 0 (np.float64 power, MCTS.py:607-608): exp(y * log x); x == 0 -> 0 for y > 0.  Not libm's pow bit for bit
+// (relative error ~ |y ln x| * 2^-52); used only for move-sampling weights, where that moves a cdf step by < 1e-13.
+GAZ_DEV double dpow(double x, double y) {
+    if (x == 0.0) return y > 0.0 ? 0.0 : 1.0;
+    if (x == 1.0 || y == 0.0) return 1.0;
+    return dexp(y * dlog(x));
+}
+
 // standard normal, Marsaglia polar method; attempt = running Philox sub-counter of this lane's variate
 GAZ_DEV double normal(const Event& e, uint32_t lane, uint32_t& attempt) {
     for (;;) {

@@ -54,7 +54,8 @@ template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
     if (g >= E.n_games || lane_id() != 0) return;
     GameState<G>& gs = E.games[g];
     memset(&gs, 0, sizeof(gs));
-    gs.phase = PH_NEW_GAME; gs.pend_kind = PEND_NONE; gs.game_seq = (uint32_t)first_seq; gs.host_move = -1; gs.winner = RUNNING;
+    gs.phase = (E.games_budget > 0 && (long long)g >= E.games_budget) ? PH_HALT : PH_NEW_GAME;     // fewer games wanted than slots
+    gs.pend_kind = PEND_NONE; gs.game_seq = (uint32_t)first_seq; gs.host_move = -1; gs.winner = RUNNING;
     E.trees[g * 2].root = -1; E.trees[g * 2 + 1].root = -1;
 }
 
@@ -94,6 +95,52 @@ template <class G> GAZ_KERNEL k_start_search(DevParams<G> E) {      // PH_IDLE -
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
     if (E.games[g].phase == PH_IDLE) E.games[g].phase = PH_ROOT;
+}
+
+// Game-rules probe (gaz_engine_probe_rules): one wavefront per position, the position given as an action history from the empty
+// board.  Runs the DEVICE rule code the search uses — landing_cell / wins_after (do_action_MCTS + check_win_MCTS), build_legal
+// (get_legal_actions_MCTS), encode_input (get_input_state_MCTS), terminal_probe (get_terminal_actions_fn), make_priors without
+// noise (get_legal_actions_policy_MCTS, normalize=True) — so the reference's Game classes can be compared with it directly.
+template <class G> GAZ_KERNEL k_probe_rules(DevParams<G> E, const int32_t* actions, const int32_t* n_actions, int n_pos, int stride,
+                                            int8_t* o_board, uint8_t* o_legal, int32_t* o_winner, int8_t* o_input, int32_t* o_term,
+                                            const float* policy_in, float* o_policy) {
+    GAZ_SHARED Scratch<G> S;
+    const int p = block_id();
+    if (p >= n_pos) return;
+    const int n = n_actions[p];
+    for (int c = lane_id(); c < G::BPAD; c += WAVE) S.board[c] = 0;
+    wave_sync();
+    int player = -1, winner = RUNNING;
+    for (int i = 0; i < n; ++i) {
+        const int a = actions[(size_t)p * stride + i];
+        if (!action_legal<G>(S.board, a)) { if (lane_id() == 0) o_winner[p] = -99; return; }   // not a legal history
+        const int cell = landing_cell<G>(S.board, a);
+        const bool win = wins_after<G>(S.board, cell, player);
+        const int empties = G::DRAWS ? count_empty<G>(S.board) : 2;
+        winner = win ? player : ((G::DRAWS && empties == 1) ? 0 : RUNNING);        // check_win after this move
+        wave_sync();
+        if (lane_id() == 0) S.board[cell] = (int8_t)player;
+        wave_sync();
+        player = -player;
+    }
+    for (int c = lane_id(); c < G::HW; c += WAVE) o_board[(size_t)p * G::HW + c] = S.board[c];
+    const int n_legal = build_legal<G>(S.board, S.legal);
+    for (int a = lane_id(); a < G::A; a += WAVE) { o_legal[(size_t)p * G::A + a] = 0; o_term[(size_t)p * G::A + a] = -1; if (o_policy) o_policy[(size_t)p * G::A + a] = 0.0f; }
+    wave_sync();
+    for (int i = lane_id(); i < n_legal; i += WAVE) o_legal[(size_t)p * G::A + S.legal[i]] = 1;
+    uint8_t h3[3];
+    for (int i = 0; i < 3; ++i) h3[i] = (n - 1 - i >= 0) ? (uint8_t)actions[(size_t)p * stride + n - 1 - i] : 0;
+    encode_input<G>(S.board, -player, h3, n, o_input + (size_t)p * (G::HW * G::C));
+    if (lane_id() == 0) o_winner[p] = winner;
+    if (winner != RUNNING) return;                                                 // the search never expands a finished position
+    bool any_win;
+    const int nt = terminal_probe<G>(S.board, S.legal, n_legal, player, S.tact, S.twin, any_win, E.fast_find_win != 0);
+    for (int i = lane_id(); i < nt; i += WAVE) o_term[(size_t)p * G::A + S.tact[i]] = S.twin[i] ? 1 : 0;
+    if (policy_in && o_policy) {
+        DevParams<G> E2 = E; E2.use_dirichlet = 0;
+        make_priors<G>(E2, 0, E.games[0], E.trees[0], 0, S, policy_in + (size_t)p * G::A, n_legal);   // game / tree state: untouched without noise
+        for (int i = lane_id(); i < n_legal; i += WAVE) o_policy[(size_t)p * G::A + S.legal[i]] = S.pri[i];
+    }
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
@@ -167,6 +214,8 @@ struct gaz_engine {
     virtual int set_search_params(int, int) = 0;
     virtual int stop_search(int) = 0;
     virtual int start_search() = 0;
+    virtual int set_hyperparams(const gaz_search_hyperparams*) = 0;
+    virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
 
 template <class G> struct EngineT : gaz_engine {
@@ -240,7 +289,11 @@ template <class G> struct EngineT : gaz_engine {
             npt = own_moves * (its + 2) + 64;
         }
         E.nodes_per_tree = npt;
-        E.ring_cap = cfg.ring_capacity; E.single_tree = cfg.single_tree; E.tau_mode = -1;
+        E.ring_cap = cfg.ring_capacity; E.single_tree = cfg.single_tree;
+        E.tau = norm_tau(cfg.tau); E.no_gumbel_noise = cfg.no_gumbel_noise; E.first_game_seq = cfg.first_game_seq;
+        if (cfg.games_budget < 0) return fail("games_budget must be >= 0");
+        if (cfg.games_budget > 0 && cfg.sync_moves) return fail("games_budget needs continuous self-play (sync_moves = 0)");
+        E.games_budget = cfg.games_budget;
         if (cfg.n_opening < 0 || cfg.n_opening > 8) return fail("at most 8 opening_actions");
         E.n_opening = cfg.n_opening;
         for (int i = 0; i < cfg.n_opening; ++i) {
@@ -279,12 +332,8 @@ template <class G> struct EngineT : gaz_engine {
         if (!gumbel) {
             double* tb = nullptr;
             if (dalloc(&tb, (size_t)2 * PUCT_TABLE_N)) return 1;
-#ifdef GAZ_HOST_EMU
-            GAZ_LAUNCH(k_init_puct_table<0>, 1, 1, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
-#else
-            GAZ_LAUNCH(k_init_puct_table<0>, (PUCT_TABLE_N + 255) / 256, 256, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
-#endif
             E.puct_table = tb;
+            if (init_puct_table()) return 1;
         }
         if (dalloc(&E.stats, 8)) return 1;
         if (dalloc(&E.error, 4)) return 1;
@@ -294,7 +343,7 @@ template <class G> struct EngineT : gaz_engine {
         std::string e2;
         eval = make_evaluator(cfg, G::H, G::W, G::C, G::A, &e2);
         if (!eval && cfg.evaluator != GAZ_EVAL_EXTERNAL) return fail("evaluator: " + e2);
-        GAZ_LAUNCH(k_init_games<G>, n, WAVE, stream, E, 0);
+        GAZ_LAUNCH(k_init_games<G>, n, WAVE, stream, E, (int)cfg.first_game_seq);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
@@ -571,9 +620,77 @@ template <class G> struct EngineT : gaz_engine {
     }
     int start_search() override { GAZ_LAUNCH(k_start_search<G>, E.n_games, WAVE, stream, E); HIP_OK(hipGetLastError()); return 0; }
     int stop_search(int stop) override { E.stop_search = stop != 0; return 0; }
+    // tau != 0 and tau <= 5e-3 -> 0 (MCTS.py:116-120,163-168); negative = Self_Play's schedule
+    static double norm_tau(double tau) { return tau < 0.0 ? -1.0 : ((tau != 0.0 && tau <= 5e-3) ? 0.0 : tau); }
     int set_search_params(int run_iterations, int tau_mode) override {
         if (run_iterations > 0) E.run_iterations = run_iterations;
-        E.tau_mode = tau_mode;
+        E.tau = tau_mode < 0 ? -1.0 : (double)tau_mode;
+        return 0;
+    }
+    int init_puct_table() {
+        double* tb = const_cast<double*>(E.puct_table);
+#ifdef GAZ_HOST_EMU
+        GAZ_LAUNCH(k_init_puct_table<0>, 1, 1, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
+#else
+        GAZ_LAUNCH(k_init_puct_table<0>, (PUCT_TABLE_N + 255) / 256, 256, stream, tb, E.c_init, E.c_base, PUCT_TABLE_N);
+#endif
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    // MCTS.update_hyperparams (MCTS.py:134-168: invalid values are ignored with a warning there, rejected here) and
+    // MCTS_Gumbel.update_hyperparams (MCTS_Gumbel.py:186-210); kernels read DevParams per launch, so the next wave sees them
+    int set_hyperparams(const gaz_search_hyperparams* hp) override {
+        if (!hp || hp->struct_size != sizeof(gaz_search_hyperparams)) return fail("set_hyperparams: struct_size does not match this library's gaz_search_hyperparams");
+        auto given = [](double v) { return v == v; };
+        if (given(hp->c_puct_init) && hp->c_puct_init < 0.0) return fail("c_puct_init cannot be negative");
+        if (given(hp->c_puct_base) && hp->c_puct_base <= 0.0) return fail("c_puct_base must be positive");
+        if (given(hp->dirichlet_alpha) && hp->dirichlet_alpha <= 0.0) return fail("dirichlet_alpha must be positive");
+        if (given(hp->dirichlet_epsilon) && (hp->dirichlet_epsilon < 0.0 || hp->dirichlet_epsilon >= 1.0)) return fail("dirichlet_epsilon must be in [0, 1)");
+        if (hp->gumbel_m >= 0 && cfg.search == GAZ_SEARCH_GUMBEL && hp->gumbel_m < 2) return fail("Gumbel search needs m >= 2");
+        bool table = false;
+        if (given(hp->c_puct_init)) { E.c_init = hp->c_puct_init; table = true; }
+        if (given(hp->c_puct_base)) { E.c_base = hp->c_puct_base; table = true; }
+        if (given(hp->dirichlet_alpha)) E.alpha = (double)(float)hp->dirichlet_alpha;
+        if (given(hp->dirichlet_epsilon)) { E.eps = hp->dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - hp->dirichlet_epsilon); }
+        if (hp->use_dirichlet >= 0) E.use_dirichlet = hp->use_dirichlet != 0;
+        if (given(hp->tau)) E.tau = norm_tau(hp->tau);
+        if (hp->gumbel_m >= 0) E.gumbel_m = hp->gumbel_m;
+        if (given(hp->c_visit)) E.c_visit = hp->c_visit;
+        if (given(hp->c_scale)) E.c_scale = hp->c_scale;
+        if (hp->run_iterations > 0) E.run_iterations = hp->run_iterations;
+        if (table && E.puct_table) return init_puct_table();
+        return 0;
+    }
+    int8_t* pr_board = nullptr; uint8_t* pr_legal = nullptr; int32_t* pr_winner = nullptr; int8_t* pr_input = nullptr; int32_t* pr_term = nullptr;
+    int32_t* pr_actions = nullptr; int32_t* pr_n = nullptr; float* pr_pin = nullptr; float* pr_pout = nullptr; int pr_cap = 0, pr_stride = 0;
+    int probe_rules(const int32_t* actions, const int32_t* n_actions, int n_pos, int stride, int8_t* o_board, uint8_t* o_legal,
+                    int32_t* o_winner, int8_t* o_input, int32_t* o_term, const float* policy_in, float* o_policy) override {
+        if (n_pos <= 0 || stride <= 0 || stride > G::MAXT || !actions || !n_actions) return fail("probe_rules: bad arguments");
+        for (int p = 0; p < n_pos; ++p) {
+            if (n_actions[p] < 0 || n_actions[p] > stride) return fail("probe_rules: history longer than stride");
+            for (int i = 0; i < n_actions[p]; ++i) { const int a = actions[(size_t)p * stride + i]; if (a < 0 || a >= G::A) return fail("probe_rules: action out of range"); }
+        }
+        if (n_pos > pr_cap || stride > pr_stride) {                      // scratch grows, never shrinks (freed with the engine)
+            const size_t n = (size_t)n_pos, st = (size_t)G::MAXT;
+            if (dalloc(&pr_board, n * G::HW) || dalloc(&pr_legal, n * G::A) || dalloc(&pr_winner, n) || dalloc(&pr_input, n * G::HW * G::C) ||
+                dalloc(&pr_term, n * G::A) || dalloc(&pr_actions, n * st) || dalloc(&pr_n, n) || dalloc(&pr_pin, n * G::A) || dalloc(&pr_pout, n * G::A)) return 1;
+            pr_cap = n_pos; pr_stride = G::MAXT;
+        }
+        const size_t n = (size_t)n_pos;
+        HIP_OK(hipMemcpyAsync(pr_actions, actions, n * stride * 4, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(pr_n, n_actions, n * 4, hipMemcpyHostToDevice, stream));
+        const bool pol = policy_in && o_policy;
+        if (pol) HIP_OK(hipMemcpyAsync(pr_pin, policy_in, n * G::A * 4, hipMemcpyHostToDevice, stream));
+        GAZ_LAUNCH(k_probe_rules<G>, n_pos, WAVE, stream, E, (const int32_t*)pr_actions, (const int32_t*)pr_n, n_pos, stride, pr_board, pr_legal,
+                   pr_winner, pr_input, pr_term, pol ? (const float*)pr_pin : (const float*)nullptr, pol ? pr_pout : (float*)nullptr);
+        HIP_OK(hipGetLastError());
+        if (o_board) HIP_OK(hipMemcpyAsync(o_board, pr_board, n * G::HW, hipMemcpyDeviceToHost, stream));
+        if (o_legal) HIP_OK(hipMemcpyAsync(o_legal, pr_legal, n * G::A, hipMemcpyDeviceToHost, stream));
+        if (o_winner) HIP_OK(hipMemcpyAsync(o_winner, pr_winner, n * 4, hipMemcpyDeviceToHost, stream));
+        if (o_input) HIP_OK(hipMemcpyAsync(o_input, pr_input, n * G::HW * G::C, hipMemcpyDeviceToHost, stream));
+        if (o_term) HIP_OK(hipMemcpyAsync(o_term, pr_term, n * G::A * 4, hipMemcpyDeviceToHost, stream));
+        if (pol) HIP_OK(hipMemcpyAsync(o_policy, pr_pout, n * G::A * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
     int dominant(char* name, int cap, double* flops) override {
@@ -600,8 +717,18 @@ template <class G> struct EngineT : gaz_engine {
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
+int gaz_engine_abi_version(void) { return GAZ_ENGINE_ABI_VERSION; }
+int gaz_engine_config_size(void) { return (int)sizeof(gaz_engine_config); }
+
 int gaz_engine_create(const gaz_engine_config* cfg, gaz_engine** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return 1; }
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(gaz_engine_config)) {
+        g_create_error = "gaz_engine_config.struct_size is " + std::to_string(cfg->struct_size) + ", this library's gaz_engine_config has " +
+                         std::to_string(sizeof(gaz_engine_config)) + " bytes (ABI version " + std::to_string(GAZ_ENGINE_ABI_VERSION) +
+                         "): rebuild the binding from include/gaz_engine.h";
+        return 1;
+    }
     gaz_engine* h = nullptr;
     switch (cfg->game) {
         case GAZ_GAME_TICTACTOE: h = new EngineT<Game<GAME_TTT>>(); break;
@@ -638,6 +765,11 @@ int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions,
 int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode) { return h->set_search_params(run_iterations, tau_mode); }
 int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(stop); }
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
+int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
+int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,
+                           uint8_t* legal, int32_t* winner, int8_t* input, int32_t* terminal, const float* policy_in, float* policy_out) {
+    return h->probe_rules(actions, n_actions, n_positions, stride, board, legal, winner, input, terminal, policy_in, policy_out);
+}
 int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops) { return h->dominant(name, cap, flops); }
 int gaz_engine_timing_get(gaz_engine* h, double* a, double* b, double* c, int64_t* d, int64_t* e) { return h->timing_get(a, b, c, d, e); }
 

@@ -512,11 +512,13 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             const int n = uni((int)r.hdr()->n_actions);
             det::Event e = make_event(E, g, gs, ts, 0, det::P_GUMBEL);
             for (int i = lane_id(); i < n; i += WAVE) {
-                gu.top_logits[i] = (float)((double)r.P()[i] + det::gumbel(e, (uint32_t)i));     // use_gumbel_noise=True (Self_Play.py:64)
+                // use_gumbel_noise=True (Self_Play.py:64): logits + np.random.gumbel, cast to f32; False (the class default,
+                // MCTS_Gumbel.py:157,592-596): the f32 logit priors as they are, and no draw
+                gu.top_logits[i] = E.no_gumbel_noise ? r.P()[i] : (float)((double)r.P()[i] + det::gumbel(e, (uint32_t)i));
                 gu.top_ids[i] = (uint8_t)i; gu.top_mean[i] = r.W()[i];
             }
             if (lane_id() == 0) {
-                ts.event += 1;
+                if (!E.no_gumbel_noise) ts.event += 1;
                 gu.m_eff = E.gumbel_m < len_legal ? E.gumbel_m : len_legal; gu.phase = 0; gu.n_top = n; gu.cur_iter = 0;
                 gu.cand = 0; gu.stage = 0; gu.sims_left = 0; gu.pend_counts = 0;
             }

@@ -41,7 +41,10 @@ template <class G> struct DevParams {
     int32_t fast_find_win;     // MCTS(fast_find_win=True): keep only the first winning move of a position (MCTS.py:282-283)
     int32_t g_stablemax;       // Gumbel: activation_fn = "stablemax" in deterministic_selection (Self_Play.py:69)
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
-    int32_t tau_mode;          // -1: Self_Play's exploration schedule; 0 / 1: tau fixed by the caller (MCTS.update_hyperparams)
+    double tau;                // < 0: Self_Play's exploration schedule (tau 1 / 0); >= 0: tau fixed by the caller (MCTS(tau=...), update_hyperparams)
+    int32_t no_gumbel_noise;   // MCTS_Gumbel(use_gumbel_noise=False)
+    uint32_t first_game_seq;   // game_seq of every slot's first game (resume: games already in the replay file)
+    long long games_budget;    // > 0: slot g plays its k-th game iff k * n_games + g < games_budget, then halts
     int32_t n_opening, opening_actions[8];   // train_config["opening_actions"] (Self_Play.py:130-140)
     double opening_weights[8];
     float one_minus_eps;
@@ -718,9 +721,15 @@ template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState
         for (int i = lane_id(); i < n; i += WAVE) { uint32_t v = r.N()[i]; if (bi == 0x7fffffff || v > bv) { bv = v; bi = i; } }
         wave_argmax_u32(bv, bi);
         chosen = uni(bi);
-    } else {                                                           // tau == 1 (MCTS.py:606-612), float64
-        const double den = (double)ts.root_visits;
-        for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)r.N()[i] / den;
+    } else {                                                           // tau > 0 (MCTS.py:606-612), float64: N^(1/tau) / visits^(1/tau)
+        const double ex = (E.tau > 0.0) ? 1.0 / E.tau : 1.0;           // Self_Play's schedule only ever sets tau = 1
+        if (ex == 1.0) {                                               // x ** 1.0 == x exactly
+            const double den = (double)ts.root_visits;
+            for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)r.N()[i] / den;
+        } else {                                                       // det::dpow stands in for libm pow (< 1e-14 relative: the sampled
+            const double den = det::dpow((double)ts.root_visits, ex);  // move differs only if u lands within that of a cdf step)
+            for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = det::dpow((double)r.N()[i], ex) / den;
+        }
         wave_sync();
         const double s = det::np_pairwise_sum<double>(S.gam, n);
         double acc = 0.0, last = 0.0;
@@ -774,7 +783,12 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
     }
     if (lane_id() == 0) {
         if (E.sync_moves) gs.phase = PH_HALT;
-        else { gs.game_seq += 1; gs.phase = PH_NEW_GAME; }
+        else {
+            gs.game_seq += 1;
+            // a generation = the first games_budget games STARTED, each run to its end (Self_Play.py:346-408): stop restarting
+            const long long k = (long long)(gs.game_seq - E.first_game_seq);
+            gs.phase = (E.games_budget > 0 && k * (long long)E.n_games + (long long)g >= E.games_budget) ? PH_HALT : PH_NEW_GAME;
+        }
     }
     wave_sync();
     return true;
@@ -838,7 +852,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                 const int num = gs.n_hist;
                 gs.tau_on[0] = (num % 2 == 0 && num / 2 < E.explore_first) ? 1 : 0;
                 gs.tau_on[1] = ((num + 1) % 2 == 0 && (num + 1) / 2 < E.explore_second) ? 1 : 0;
-                if (E.tau_mode >= 0) { gs.tau_on[0] = E.tau_mode; gs.tau_on[1] = E.tau_mode; }
+                if (E.tau >= 0.0) { gs.tau_on[0] = E.tau != 0.0; gs.tau_on[1] = gs.tau_on[0]; }
                 gs.runner = E.single_tree ? 0 : ((gs.next_player == -1) ? 0 : 1);
                 int lim = E.run_iterations;
                 if (len_legal == 1) lim = 1; else if (lim < len_legal) lim = len_legal * 3;

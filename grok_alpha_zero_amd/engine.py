@@ -19,8 +19,11 @@ EVAL_HASH, EVAL_RESNET, EVAL_EXTERNAL = 0, 1, 2
 PH_WAIT_HOST, PH_HALT, PH_IDLE = 5, 8, 9
 
 
-class EngineConfig(C.Structure):
-    _fields_ = [("game", C.c_int32), ("search", C.c_int32), ("n_games", C.c_int32), ("run_iterations", C.c_int32),
+ABI_VERSION = 2               # GAZ_ENGINE_ABI_VERSION of include/gaz_engine.h this binding was written against
+
+
+class EngineConfig(C.Structure):       # gaz_engine_config — tests/test_abi.py checks names, order and sizeof against the header
+    _fields_ = [("struct_size", C.c_uint32), ("game", C.c_int32), ("search", C.c_int32), ("n_games", C.c_int32), ("run_iterations", C.c_int32),
                 ("max_actions", C.c_int32), ("num_explore_actions_first", C.c_int32), ("num_explore_actions_second", C.c_int32),
                 ("c_puct_init", C.c_double), ("c_puct_base", C.c_double), ("dirichlet_alpha", C.c_double),
                 ("dirichlet_epsilon", C.c_double), ("use_dirichlet", C.c_int32), ("create_new_root", C.c_int32),
@@ -29,7 +32,14 @@ class EngineConfig(C.Structure):
                 ("device", C.c_int32), ("net_blocks", C.c_int32), ("net_filters", C.c_int32), ("policy_is_logits", C.c_int32),
                 ("gumbel_m", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double), ("compact_trees", C.c_int32),
                 ("single_tree", C.c_int32), ("n_opening", C.c_int32), ("opening_actions", C.c_int32 * 8),
-                ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32), ("fast_find_win", C.c_int32)]
+                ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32), ("fast_find_win", C.c_int32),
+                ("no_gumbel_noise", C.c_int32), ("first_game_seq", C.c_uint32), ("games_budget", C.c_int64), ("tau", C.c_double)]
+
+
+class SearchHyperparams(C.Structure):  # gaz_search_hyperparams
+    _fields_ = [("struct_size", C.c_uint32), ("use_dirichlet", C.c_int32), ("c_puct_init", C.c_double), ("c_puct_base", C.c_double),
+                ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double), ("tau", C.c_double), ("gumbel_m", C.c_int32),
+                ("run_iterations", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double)]
 
 
 class Tensor(C.Structure):
@@ -53,6 +63,10 @@ def load_library(lib_path=None):
                            "there is no CPU fallback")
     L = C.CDLL(path)
     H = C.c_void_p
+    L.gaz_engine_abi_version.restype = C.c_int; L.gaz_engine_config_size.restype = C.c_int
+    if L.gaz_engine_abi_version() != ABI_VERSION or L.gaz_engine_config_size() != C.sizeof(EngineConfig):
+        raise RuntimeError(f"{path}: ABI version {L.gaz_engine_abi_version()} / config size {L.gaz_engine_config_size()} does not match "
+                           f"this binding ({ABI_VERSION} / {C.sizeof(EngineConfig)}): rebuild the library")
     L.gaz_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(H)]
     L.gaz_engine_destroy.argtypes = [H]; L.gaz_engine_destroy.restype = None
     L.gaz_engine_last_error.argtypes = [H]; L.gaz_engine_last_error.restype = C.c_char_p
@@ -77,12 +91,15 @@ def load_library(lib_path=None):
     L.gaz_engine_set_search_params.argtypes = [H, C.c_int32, C.c_int32]
     L.gaz_engine_stop_search.argtypes = [H, C.c_int32]
     L.gaz_engine_start_search.argtypes = [H]
+    L.gaz_engine_set_hyperparams.argtypes = [H, C.POINTER(SearchHyperparams)]
+    L.gaz_engine_probe_rules.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
-              "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search"):
+              "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search",
+              "set_hyperparams", "probe_rules"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -101,19 +118,26 @@ class SelfPlayEngine:
                  create_new_root=False, sync_moves=False, nodes_per_tree=0, ring_capacity=None, slot_offset=0,
                  evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
                  policy_is_logits=False, max_tree_sims_per_wave=0, gumbel_m=0, c_visit=50.0, c_scale=1.0,
-                 compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, fast_find_win=False, lib_path=None):
+                 compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, fast_find_win=False,
+                 use_gumbel_noise=True, first_game_seq=0, games_budget=0, tau=-1.0, lib_path=None):
         self.L = load_library(lib_path)
         self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
         self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
         self.n_games = n_games
         if ring_capacity is None:
             ring_capacity = 2 * n_games
-        self.cfg = EngineConfig(self.game_id, search, n_games, run_iterations, max_actions, num_explore_actions_first,
-                                num_explore_actions_second, c_puct_init, c_puct_base, dirichlet_alpha, dirichlet_epsilon,
-                                int(use_dirichlet), int(create_new_root), int(sync_moves), nodes_per_tree, ring_capacity,
-                                seed, slot_offset, evaluator, hash_salt, device, net_blocks, net_filters, int(policy_is_logits),
-                                gumbel_m, c_visit, c_scale, compact_trees, int(single_tree), 0, (C.c_int32 * 8)(), (C.c_double * 8)(),
-                                max_tree_sims_per_wave, int(eval_cache_log2), int(gumbel_stablemax), int(fast_find_win))
+        self.cfg = EngineConfig(struct_size=C.sizeof(EngineConfig), game=self.game_id, search=search, n_games=n_games,
+                                run_iterations=run_iterations, max_actions=max_actions, num_explore_actions_first=num_explore_actions_first,
+                                num_explore_actions_second=num_explore_actions_second, c_puct_init=c_puct_init, c_puct_base=c_puct_base,
+                                dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon, use_dirichlet=int(use_dirichlet),
+                                create_new_root=int(create_new_root), sync_moves=int(sync_moves), nodes_per_tree=nodes_per_tree,
+                                ring_capacity=ring_capacity, seed=seed, slot_offset=slot_offset, evaluator=evaluator, hash_salt=hash_salt,
+                                device=device, net_blocks=net_blocks, net_filters=net_filters, policy_is_logits=int(policy_is_logits),
+                                gumbel_m=gumbel_m, c_visit=c_visit, c_scale=c_scale, compact_trees=compact_trees, single_tree=int(single_tree),
+                                max_tree_sims_per_wave=max_tree_sims_per_wave, eval_cache_log2=int(eval_cache_log2),
+                                gumbel_stablemax=int(gumbel_stablemax), fast_find_win=int(fast_find_win),
+                                no_gumbel_noise=int(not use_gumbel_noise), first_game_seq=int(first_game_seq), games_budget=int(games_budget),
+                                tau=float(tau))
         for i, (a, w) in enumerate(opening_actions or []):       # [(action index, weight)] — train_config["opening_actions"]
             self.cfg.opening_actions[i] = int(a); self.cfg.opening_weights[i] = float(w); self.cfg.n_opening = i + 1
         self.h = C.c_void_p()
@@ -189,6 +213,39 @@ class SelfPlayEngine:
 
     def set_search_params(self, run_iterations=0, tau_mode=-1):
         self._ck(self.L.gaz_engine_set_search_params(self.h, int(run_iterations), int(tau_mode)))
+
+    def set_hyperparams(self, *, c_puct_init=None, c_puct_base=None, dirichlet_alpha=None, dirichlet_epsilon=None, use_dirichlet=None,
+                        tau=None, m=None, c_visit=None, c_scale=None, run_iterations=None):
+        """MCTS.update_hyperparams / MCTS_Gumbel.update_hyperparams (MCTS.py:134-168, MCTS_Gumbel.py:186-210); None = unchanged."""
+        nan = float("nan")
+        d = lambda v: nan if v is None else float(v)
+        hp = SearchHyperparams(struct_size=C.sizeof(SearchHyperparams), use_dirichlet=-1 if use_dirichlet is None else int(bool(use_dirichlet)),
+                               c_puct_init=d(c_puct_init), c_puct_base=d(c_puct_base), dirichlet_alpha=d(dirichlet_alpha),
+                               dirichlet_epsilon=d(dirichlet_epsilon), tau=d(tau), gumbel_m=-1 if m is None else int(m),
+                               run_iterations=0 if run_iterations is None else int(run_iterations), c_visit=d(c_visit), c_scale=d(c_scale))
+        self._ck(self.L.gaz_engine_set_hyperparams(self.h, C.byref(hp)))
+
+    def probe_rules(self, histories, policy=None):
+        """The device's game rules on a list of positions (each a list of action indices from the empty board): dict of board
+        [n,H,W], legal [n,A] bool, winner [n], input [n,H,W,C], terminal [n,A] (-1 / 0 draw / 1 win) and, with `policy` [n,A],
+        legal_policy [n,A] (get_legal_actions_policy_MCTS, normalize=True).  Guide.py:135-283, Game_Tester.py:297-405."""
+        n = len(histories)
+        stride = max(1, max((len(h) for h in histories), default=1))
+        acts = np.zeros((n, stride), np.int32); na = np.zeros(n, np.int32)
+        for i, h in enumerate(histories):
+            na[i] = len(h); acts[i, :len(h)] = np.asarray(h, np.int32).reshape(-1)
+        out = dict(board=np.zeros((n, self.H, self.W), np.int8), legal=np.zeros((n, self.A), np.uint8), winner=np.zeros(n, np.int32),
+                   input=np.zeros((n, self.H, self.W, self.Cc), np.int8), terminal=np.zeros((n, self.A), np.int32))
+        pin = pout = None
+        if policy is not None:
+            pin = np.ascontiguousarray(policy, np.float32); assert pin.shape == (n, self.A)
+            pout = np.zeros((n, self.A), np.float32); out["legal_policy"] = pout
+        self._ck(self.L.gaz_engine_probe_rules(self.h, acts.ctypes.data, na.ctypes.data, n, stride, out["board"].ctypes.data,
+                                               out["legal"].ctypes.data, out["winner"].ctypes.data, out["input"].ctypes.data,
+                                               out["terminal"].ctypes.data, None if pin is None else pin.ctypes.data,
+                                               None if pout is None else pout.ctypes.data))
+        out["legal"] = out["legal"].astype(bool)
+        return out
 
     def reset_games(self, slots=None):
         if slots is None:

@@ -83,6 +83,13 @@ class _EngineSearch:
             if stopped:
                 eng.stop_search(False)
 
+    def _child_terminal(self, indices):
+        """child.is_terminal of the root's children (MCTS.py:49,414,600): None while the game runs on, the winner (-1 / 1) or 0 for a
+        draw when the move ends it — from the device's own rule code (probe_rules)."""
+        hist = [_to_index(self._name, a) for a in self.game.action_history]
+        w = self._eng.probe_rules([hist + [int(a)] for a in indices])["winner"] if len(indices) else []
+        return {int(a): (None if int(x) == -2 else int(x)) for a, x in zip(indices, w)}
+
     def prune_tree(self, action, create_new_root=False):
         """game.do_action(action) was already called by the user (Self_Play.py:142-150); replay it on the device and re-root."""
         if create_new_root:
@@ -108,13 +115,33 @@ class MCTS(_EngineSearch):
                      dirichlet_epsilon=dirichlet_epsilon, use_dirichlet=use_dirichlet, hash_salt=hash_salt, search=SEARCH_PUCT,
                      fast_find_win=bool(fast_find_win))
 
-    def update_hyperparams(self, **kwargs):                                              # MCTS.py:134-168 (tau only; the rest is fixed at creation)
+    def update_hyperparams(self, **kwargs):
+        """MCTS.py:134-168: invalid values are ignored with a warning, valid ones take effect at the next simulation."""
+        upd = {}
+        v = kwargs.get("c_puct_init")
+        if v is not None:
+            if v < 0.0: warn(f"c_puct_init value is invalid, {v} cannot be negative.")
+            else: self.c_puct_init = upd["c_puct_init"] = v
+        v = kwargs.get("c_puct_base")
+        if v is not None:
+            if v <= 0: warn("c_puct_base cannot be negative")
+            else: self.c_puct_base = upd["c_puct_base"] = v
+        v = kwargs.get("dirichlet_alpha")
+        if v is not None:
+            if v <= 0.0: warn("dirichlet_alpha cannot be less than or equal to 0")
+            else: self.dirichlet_alpha = upd["dirichlet_alpha"] = v
+        v = kwargs.get("dirichlet_epsilon")
+        if v is not None:
+            if v < 0.0 or v >= 1.0: warn("dirichlet_epsilon cannot be negative nor bigger than 1")
+            else: self.dirichlet_epsilon = upd["dirichlet_epsilon"] = v
         tau = kwargs.get("tau")
         if tau is not None:
-            self.tau = 0.0 if (tau != 0.0 and tau <= 5e-3) else tau
-        for k in ("c_puct_init", "c_puct_base", "dirichlet_alpha", "dirichlet_epsilon"):
-            if kwargs.get(k) is not None and kwargs[k] != getattr(self, k):
-                warn(f"{k} is fixed when the engine is created; ignoring the update")
+            if tau != 0.0 and tau <= 5e-3:
+                warn("Tau can't be less than 5e-3. Changing tau = 0.0")
+                tau = 0.0
+            self.tau = tau                                                               # handed to the engine by the next run()
+        if upd:
+            self._eng.set_hyperparams(**upd)
 
     def run(self, iteration_limit=None, time_limit=None, use_bar=True):
         """-> (move, rows); row = [action, N / sum N, W / N, W, N, P, root.visits, is_terminal] sorted by visits (MCTS.py:591-618)."""
@@ -128,15 +155,15 @@ class MCTS(_EngineSearch):
             iteration_limit = 3 * n_legal                                                # MCTS.py:545-546 (None would never stop there)
         if iteration_limit is None:
             iteration_limit = self._MAX_TIMED_ITERATIONS                                 # time-limited only: bounded by the node arena
-        if self.tau not in (0.0, 1.0):
-            raise NotImplementedError("tau must be 0 or 1")
-        self._eng.set_search_params(int(min(iteration_limit, self._MAX_TIMED_ITERATIONS)), int(self.tau))
+        # tau = 0: most visited move; otherwise sample with weights N^(1/tau) in float64 (MCTS.py:602-612)
+        self._eng.set_hyperparams(run_iterations=int(min(iteration_limit, self._MAX_TIMED_ITERATIONS)), tau=float(self.tau))
         self._pump(None if time_limit is None else time.time() + float(time_limit))
         st = self._eng.root_stats()
         N, Wv, P, rv = st["N"][0], st["W"][0], st["P"][0], int(st["root_visits"][0])
         idx = [a for a in np.argsort(-P, kind="stable") if N[a] > 0 or P[a] > 0]        # child order = descending prior
         total = float(N.sum())
-        rows = [[_to_action(self._name, a), N[a] / total, float(Wv[a]) / float(N[a]), Wv[a], N[a], P[a], rv, None] for a in idx]
+        term = self._child_terminal(idx)
+        rows = [[_to_action(self._name, a), N[a] / total, float(Wv[a]) / float(N[a]), Wv[a], N[a], P[a], rv, term[a]] for a in idx]
         rows.sort(key=lambda r: r[4], reverse=True)
         return _to_action(self._name, int(st["chosen"][0])), rows
 
@@ -146,16 +173,17 @@ class MCTS_Gumbel(_EngineSearch):
                  activation_fn="softmax", fast_find_win=False, *, seed=None, hash_salt=0, max_actions=None, lib_path=None):
         if activation_fn not in ("softmax", "stablemax"):
             raise ValueError("activation_fn must be 'softmax' or 'stablemax'")
-        if not use_gumbel_noise:
-            warn("the engine always adds Gumbel noise at the root (Self_Play.py:64 uses use_gumbel_noise=True)")
-        self.m, self.c_visit, self.c_scale = m, c_visit, c_scale
+        self.m, self.c_visit, self.c_scale, self.use_gumbel_noise = m, c_visit, c_scale, use_gumbel_noise
         self._attach(game, session, seed, lib_path, max_actions=max_actions or int(np.prod(game.board.shape)), hash_salt=hash_salt,
-                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale, gumbel_stablemax=activation_fn == "stablemax", fast_find_win=bool(fast_find_win))
+                     search=SEARCH_GUMBEL, gumbel_m=m, c_visit=c_visit, c_scale=c_scale, gumbel_stablemax=activation_fn == "stablemax",
+                     fast_find_win=bool(fast_find_win), use_gumbel_noise=bool(use_gumbel_noise))
 
-    def update_hyperparams(self, *args, **kwargs):
-        for k in ("m", "c_visit", "c_scale"):
-            if kwargs.get(k) is not None and kwargs[k] != getattr(self, k):
-                warn(f"{k} is fixed when the engine is created; ignoring the update")
+    def update_hyperparams(self, *args, **kwargs):                                       # MCTS_Gumbel.py:186-210
+        upd = {k: kwargs[k] for k in ("m", "c_visit", "c_scale") if kwargs.get(k) is not None}
+        for k, v in upd.items():
+            setattr(self, k, v)
+        if upd:
+            self._eng.set_hyperparams(**upd)
 
     def run(self, iteration_limit=None, time_limit=None, use_bar=True):
         """-> (move, rows); row = [action, pi, mean value (pi where unvisited), W, N, logit, root.visits, is_terminal] sorted by pi."""
@@ -166,7 +194,8 @@ class MCTS_Gumbel(_EngineSearch):
         st = self._eng.root_stats()
         N, Wv, P, pi, rv = st["N"][0], st["W"][0], st["P"][0], st["policy"][0], int(st["root_visits"][0])
         legal = [_to_index(self._name, a) for a in self.game.get_legal_actions()]
-        rows = [[_to_action(self._name, a), pi[a], (float(Wv[a]) / float(N[a])) if N[a] else pi[a], Wv[a], N[a], P[a], rv, None]
+        term = self._child_terminal(legal)
+        rows = [[_to_action(self._name, a), pi[a], (float(Wv[a]) / float(N[a])) if N[a] else pi[a], Wv[a], N[a], P[a], rv, term[a]]
                 for a in legal]
         rows.sort(key=lambda r: r[1], reverse=True)
         return _to_action(self._name, int(st["chosen"][0])), rows

@@ -22,6 +22,9 @@
  *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
  *   gaz_engine_set_position    MCTS.__init__ attaching to a live game object   MCTS.py:100,132,296-313
  *   gaz_engine_set_search_params  run(iteration_limit) / update_hyperparams(tau) MCTS.py:134-168,528
+ *   gaz_engine_set_hyperparams    MCTS.update_hyperparams(c_puct_*, dirichlet_*, tau) MCTS.py:134-168;
+ *                                 MCTS_Gumbel.update_hyperparams(m, c_visit, c_scale)  MCTS_Gumbel.py:186-210
+ *   gaz_engine_probe_rules     the Game plugin's static *_MCTS functions          Guide.py:135-283, Game_Tester.py:297-405
  *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  */
@@ -40,7 +43,11 @@ enum { GAZ_EVAL_HASH = 0,      /* synthetic bit-reproducible evaluator (parity t
        GAZ_EVAL_RESNET = 1,    /* the ResNet policy/value network, HIP MFMA kernels */
        GAZ_EVAL_EXTERNAL = 2   /* caller evaluates the batch between wave_begin / wave_end */ };
 
+#define GAZ_ENGINE_ABI_VERSION 2   /* bumped whenever gaz_engine_config / gaz_search_hyperparams / an entry point changes */
+
 typedef struct {
+    uint32_t struct_size;         /* = sizeof(gaz_engine_config) of the header the caller was built against; gaz_engine_create
+                                     rejects any other value (a stale binding would otherwise be read past its end) */
     int32_t game;                 /* GAZ_GAME_* */
     int32_t search;               /* GAZ_SEARCH_* */
     int32_t n_games;              /* concurrent games on this GPU */
@@ -79,7 +86,31 @@ typedef struct {
                                      stablemax instead of softmax inside deterministic_selection (MCTS_Gumbel.py:144-148) */
     int32_t fast_find_win;        /* MCTS(fast_find_win=True) (MCTS.py:88,282-283; MCTS_Gumbel.py:313): a position with a winning
                                      move keeps only the first one (in legal-action order); Self_Play always passes False */
+    int32_t no_gumbel_noise;      /* 1: MCTS_Gumbel(use_gumbel_noise=False), the class default (MCTS_Gumbel.py:157,592-596): no Gumbel
+                                     variates are added to the root logits and no RNG event is consumed.  Self_Play passes True (:64) */
+    uint32_t first_game_seq;      /* game sequence number of the first game of every slot (RNG streams are keyed by (seed, slot,
+                                     game_seq)): a resumed generation passes the games already in the replay file so that no game
+                                     is replayed (Self_Play.py:267-272 resumes by count; its workers reseed from OS entropy, :221) */
+    int64_t games_budget;         /* continuous self-play only: > 0 = play exactly this many games — slot g plays its k-th game
+                                     (k = game_seq - first_game_seq) iff k * n_games + g < games_budget, then halts — so a generation
+                                     is the FIRST games_budget games STARTED, all run to completion (Self_Play.py:346-408), not the
+                                     first ones to finish; 0 = slots restart forever */
+    double tau;                   /* MCTS(tau=...) (MCTS.py:116-120,602-610): < 0 = Self_Play's schedule (tau 1 for the first
+                                     num_explore_actions plies of each player, then 0); 0 = most visited move; > 0 = sample with
+                                     weights N^(1/tau).  gaz_engine_set_hyperparams changes it between runs */
 } gaz_engine_config;
+
+/* MCTS.update_hyperparams(**kwargs) (MCTS.py:134-168) / MCTS_Gumbel.update_hyperparams (MCTS_Gumbel.py:186-210): values take
+ * effect at the next launch.  A NaN double / negative int32 field means "unchanged" (kwargs.get(...) is None). */
+typedef struct {
+    uint32_t struct_size;         /* = sizeof(gaz_search_hyperparams) */
+    int32_t use_dirichlet;        /* < 0 unchanged */
+    double c_puct_init, c_puct_base, dirichlet_alpha, dirichlet_epsilon;
+    double tau;                   /* as gaz_engine_config.tau; NaN unchanged */
+    int32_t gumbel_m;             /* < 0 unchanged */
+    int32_t run_iterations;       /* <= 0 unchanged */
+    double c_visit, c_scale;
+} gaz_search_hyperparams;
 
 typedef struct {
     const char* name;             /* e.g. "stem.conv.weight" — see grok_alpha_zero_amd/net.py */
@@ -93,6 +124,8 @@ typedef struct {
     int32_t off_hdr, off_actions, off_q, off_root_visits, off_evals, off_policy, off_N, off_W, off_P;
 } gaz_record_layout;
 
+int gaz_engine_abi_version(void);                   /* GAZ_ENGINE_ABI_VERSION of the library */
+int gaz_engine_config_size(void);                   /* sizeof(gaz_engine_config) of the library */
 int gaz_engine_create(const gaz_engine_config* cfg, gaz_engine** out);
 void gaz_engine_destroy(gaz_engine* h);
 const char* gaz_engine_last_error(gaz_engine* h);   /* h may be NULL: last create() error */
@@ -121,12 +154,25 @@ int gaz_engine_write_outputs(gaz_engine* h, const float* policy, const float* va
 int gaz_engine_set_position(gaz_engine* h, int32_t slot, const int32_t* actions, int32_t n);
 /* iteration_limit of the following MCTS.run calls (<= 0: unchanged); tau_mode -1 = Self_Play schedule, 0 / 1 = fixed tau */
 int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t tau_mode);
+/* MCTS.update_hyperparams / MCTS_Gumbel.update_hyperparams for every tree of the engine (see gaz_search_hyperparams) */
+int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp);
 /* MCTS.run(time_limit=...) (MCTS.py:528-563): stop != 0 makes every running search finish its move at the next launch, as the
  * reference's `time.time() - start_time < time_limit` test does between iterations; stop = 0 re-arms.  The host owns the clock. */
 int gaz_engine_stop_search(gaz_engine* h, int32_t stop);
 
 /* sync + single_tree engines idle after set_position / apply_moves; this starts MCTS.run for the idle slots */
 int gaz_engine_start_search(gaz_engine* h);
+
+/* Game-rules probe: n_positions positions, each given as n_actions[p] action indices (row p of actions[n_positions][stride]) played
+ * from the empty board, first mover = -1.  The DEVICE rule code the search uses answers, per position: board int8 [H*W]; legal
+ * uint8 [A] mask (get_legal_actions_MCTS); winner = check_win_MCTS after the last action (-2 running, -1 / 1 winner, 0 draw; -99 =
+ * the history was not legal); input int8 [H*W*C] (get_input_state_MCTS); terminal int32 [A]: -1 not terminal, 1 the move wins, 0 it
+ * draws (get_terminal_actions_fn, MCTS.py:247-294; all -1 for a finished position); and, when policy_in f32 [n][A] is given,
+ * policy_out f32 [n][A] = get_legal_actions_policy_MCTS(..., normalize=True): policy at the legal actions / their sum, 0 elsewhere.
+ * Output pointers may be NULL.  Reference: the static *_MCTS methods of the Game plugin (Guide.py:135-283), Game_Tester.py:297-405. */
+int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride,
+                           int8_t* board, uint8_t* legal, int32_t* winner, int8_t* input, int32_t* terminal,
+                           const float* policy_in, float* policy_out);
 
 /* run the built-in evaluator on a host batch: inputs int8 [n][H*W*C] -> policy f32 [n][A], value f32 [n]; n <= n_games */
 int gaz_engine_evaluate(gaz_engine* h, const int8_t* inputs, int32_t n, float* policy, float* value, int32_t repeats, double* ms_per_batch);

@@ -145,6 +145,12 @@ static inline double gaz_exp(double x) {
 }
 
 static inline double gaz_sqrt(double x) { return __builtin_sqrt(x); } /* IEEE correctly rounded */
+/* x ** y, x >= 0: the device's stand-in for libm pow (csrc/det.hpp dpow), same operation order */
+static inline double gaz_pow(double x, double y) {
+    if (x == 0.0) return y > 0.0 ? 0.0 : 1.0;
+    if (x == 1.0 || y == 0.0) return 1.0;
+    return gaz_exp(y * gaz_log(x));
+}
 
 /* ---------------------------------------------------------------- samplers */
 /* Standard normal by the Marsaglia polar method; *attempt is the running Philox

@@ -345,7 +345,8 @@ int gaz_selfplay_game_gumbel(const gaz_sp_config* cfg, int m, double c_visit, do
     ev.event = 0; ev.tree = 0; ev.purpose = 0;
     ggumbel t; memset(&t, 0, sizeof(t));
     t.g = g; t.game_board = board; t.game_history = history; t.game_n_history = &n_history; t.game_next_player = &next_player;
-    t.eval = eval; t.eval_ctx = ctx; t.m = m; t.c_visit = c_visit; t.c_scale = c_scale; t.use_gumbel_noise = 1; t.use_softmax = (use_libm & 2) ? 0 : 1;
+    t.eval = eval; t.eval_ctx = ctx; t.m = m; t.c_visit = c_visit; t.c_scale = c_scale; t.use_gumbel_noise = (use_libm & 4) ? 0 : 1;   /* bit 2: MCTS_Gumbel(use_gumbel_noise=False), MCTS_Gumbel.py:157,592 */
+    t.use_softmax = (use_libm & 2) ? 0 : 1;
     t.ev = &ev;
     int winner = GAZ_RUNNING, T = 0, actions_count = 0; gaz_move_row rows[225]; int n_rows;
     g_create_root(&t);

@@ -157,11 +157,11 @@ def hash_eval(state_i8, A, salt):
 
 # ---------------------------------------------------------------- self-play of one game
 def selfplay_game_gumbel(game, iteration_limit, max_actions, m, c_visit, c_scale, seed, slot=0, game_seq=0, evaluator=None,
-                         hash_salt=0, use_libm=False, opening_actions=None, stablemax=False):
+                         hash_salt=0, use_libm=False, opening_actions=None, stablemax=False, gumbel_noise=True):
     """One Gumbel self-play game (MCTS_Gumbel.run(iteration_limit) per move, gumbel noise on).  stablemax=True: activation_fn =
     "stablemax" in the deterministic selection (build_config["use_stablemax"], Self_Play.py:69)."""
     return selfplay_game(game, iteration_limit, max_actions, 0, 0, 0.0, 0.0, seed, slot, game_seq, evaluator, hash_salt,
-                         use_libm=use_libm, gumbel=(m, c_visit, c_scale, bool(stablemax)), opening_actions=opening_actions)
+                         use_libm=use_libm, gumbel=(m, c_visit, c_scale, bool(stablemax), bool(gumbel_noise)), opening_actions=opening_actions)
 
 
 def selfplay_game(game, run_iterations, max_actions, explore_first, explore_second, c_puct_init, dirichlet_alpha,
@@ -194,7 +194,8 @@ def selfplay_game(game, run_iterations, max_actions, explore_first, explore_seco
             L.gaz_selfplay_game(C.byref(cfg), fn, ctxp, seed, slot, game_seq, C.byref(rec))
         else:
             L.gaz_selfplay_game_gumbel(C.byref(cfg), int(gumbel[0]), float(gumbel[1]), float(gumbel[2]), run_iterations, fn, ctxp,
-                                       seed, slot, game_seq, int(bool(use_libm)) | (2 if (len(gumbel) > 3 and gumbel[3]) else 0), C.byref(rec))
+                                       seed, slot, game_seq, int(bool(use_libm)) | (2 if (len(gumbel) > 3 and gumbel[3]) else 0) | (4 if (len(gumbel) > 4 and not gumbel[4]) else 0),
+                                       C.byref(rec))
     if evaluator is None:
         ctx = HashEvalCtx(hash_salt, A)
         play(C.cast(L.gaz_hash_eval, C.c_void_p), C.cast(C.byref(ctx), C.c_void_p))

@@ -304,9 +304,10 @@ int gaz_puct_run(gaz_puct* t, int iteration_limit, gaz_move_row* out_rows, int* 
         for (int i = 0; i < n; ++i) w[i] = (i == am) ? 1.0 : 0.0;
     } else {                                                                   /* MCTS.py:606-610 */
         double ex = 1.0 / t->tau;
-        double den = (ex == 1.0) ? (double)t->root_visits : pow((double)t->root_visits, ex);
+        /* np.float64 ** np.float64 is libm pow (use_libm); otherwise the device's exp(y log x) stand-in (gaz_pow) */
+        double den = (ex == 1.0) ? (double)t->root_visits : (g_use_libm ? pow((double)t->root_visits, ex) : gaz_pow((double)t->root_visits, ex));
         for (int i = 0; i < n; ++i) {
-            double num = (ex == 1.0) ? (double)r->child_visits[i] : pow((double)r->child_visits[i], ex);
+            double num = (ex == 1.0) ? (double)r->child_visits[i] : (g_use_libm ? pow((double)r->child_visits[i], ex) : gaz_pow((double)r->child_visits[i], ex));
             w[i] = num / den;
         }
         double s = gaz_np_sum_f64(w, n);

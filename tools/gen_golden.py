@@ -104,8 +104,9 @@ PUCT_CASES = [
 ]
 
 
-def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, max_plies, fast_find_win=False):
-    """The reference's MCTS class used on its own (Connect4/play.py, Game_Tester.py:480-513): ONE tree searches every move."""
+def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, max_plies, fast_find_win=False, taus=None, updates=None):
+    """The reference's MCTS class used on its own (Connect4/play.py, Game_Tester.py:480-513): ONE tree searches every move.
+    taus: tau per ply (general tau, MCTS.py:606-610); updates: {ply: kwargs} passed to update_hyperparams before that ply's run."""
     ref = ref_shim.load_reference()
     inj = ref_shim.activate(seed, 0, 0)
     cls = getattr(ref[GAME_CLASS[game][0]], GAME_CLASS[game][1])
@@ -113,22 +114,70 @@ def ref_single_tree_puct(game, iteration_limit, c_puct_init, alpha, seed, salt, 
     sess = ref_shim.HashSession(A, salt)
     mcts = ref["MCTS"].MCTS(g, sess, use_njit=False, c_puct_init=c_puct_init, use_dirichlet=True, dirichlet_alpha=alpha,
                             dirichlet_epsilon=0.25, tau=1.0, fast_find_win=fast_find_win)
-    acts, rN, rW, rP, rV = [], [], [], [], []
+    acts, rN, rW, rP, rV, rT = [], [], [], [], [], []
     for ply in range(max_plies):
-        mcts.update_hyperparams(tau=1.0 if ply < 4 else 0)
+        mcts.update_hyperparams(tau=(1.0 if ply < 4 else 0) if taus is None else taus[ply % len(taus)])
+        if updates and ply in updates:
+            mcts.update_hyperparams(**updates[ply])
         move, rows = mcts.run(iteration_limit=iteration_limit, use_bar=False)
-        N = np.zeros(A, np.uint32); Wv = np.zeros(A, np.float32); P = np.zeros(A, np.float32)
+        N = np.zeros(A, np.uint32); Wv = np.zeros(A, np.float32); P = np.zeros(A, np.float32); Tm = np.full(A, -9, np.int32)
         for r in rows:
-            a = action_to_index(game, r[0]); N[a] = r[4]; Wv[a] = r[3]; P[a] = r[5]
-        acts.append(action_to_index(game, move)); rN.append(N); rW.append(Wv); rP.append(P); rV.append(int(rows[0][6]))
+            a = action_to_index(game, r[0]); N[a] = r[4]; Wv[a] = r[3]; P[a] = r[5]; Tm[a] = -2 if r[7] is None else int(r[7])
+        acts.append(action_to_index(game, move)); rN.append(N); rW.append(Wv); rP.append(P); rV.append(int(rows[0][6])); rT.append(Tm)
         g.do_action(move)
         if g.check_win() != -2:
             break
         mcts.prune_tree(move)
     return dict(game=game, iteration_limit=iteration_limit, c_puct_init=c_puct_init, dirichlet_alpha=alpha, seed=seed, salt=salt,
                 actions=np.array(acts, np.int32), root_N=np.array(rN), root_W=np.array(rW), root_P=np.array(rP),
-                root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls, fast_find_win=int(fast_find_win))
+                root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls, fast_find_win=int(fast_find_win),
+                is_terminal=np.array(rT), taus=np.array(taus if taus is not None else [], np.float64),
+                update_plies=np.array(sorted(updates) if updates else [], np.int32),
+                update_json=np.array(__import__("json").dumps({str(k): v for k, v in (updates or {}).items()})))
 
+
+def ref_single_gumbel(game, iteration_limit, m, c_visit, c_scale, seed, salt, max_plies, use_gumbel_noise, updates=None):
+    """The reference's MCTS_Gumbel class on its own with use_gumbel_noise as given (the class default is False, MCTS_Gumbel.py:157);
+    a fresh object per move like Self_Play.py:151-153 — one continuing injected stream."""
+    ref = ref_shim.load_reference()
+    ref_shim.activate(seed, 0, 0)
+    cls = getattr(ref[GAME_CLASS[game][0]], GAME_CLASS[game][1])
+    g = cls(); A = g.policy_shape[0]
+    sess = ref_shim.HashSession(A, salt)
+    acts, pis, rN, rW, rP, rV = [], [], [], [], [], []
+    kw = dict(m=m, c_visit=c_visit, c_scale=c_scale)
+    for ply in range(max_plies):
+        mcts = ref["MCTS_Gumbel"].MCTS_Gumbel(g, sess, use_gumbel_noise=use_gumbel_noise, use_njit=False, **kw)
+        if updates and ply in updates:
+            mcts.update_hyperparams(**updates[ply]); kw.update(updates[ply])
+        move, rows = mcts.run(iteration_limit=iteration_limit, use_bar=False)
+        N = np.zeros(A, np.uint32); Wv = np.zeros(A, np.float32); P = np.zeros(A, np.float32); pi = np.zeros(A, np.float32)
+        for r in rows:
+            a = action_to_index(game, r[0]); N[a] = r[4]; Wv[a] = r[3]; P[a] = r[5]; pi[a] = r[1]
+        acts.append(action_to_index(game, move)); rN.append(N); rW.append(Wv); rP.append(P); pis.append(pi); rV.append(int(rows[0][6]))
+        g.do_action(move)
+        if g.check_win() != -2:
+            break
+    return dict(game=game, iteration_limit=iteration_limit, m=m, c_visit=c_visit, c_scale=c_scale, seed=seed, salt=salt,
+                use_gumbel_noise=int(use_gumbel_noise), actions=np.array(acts, np.int32), policies=np.array(pis), root_N=np.array(rN),
+                root_W=np.array(rW), root_P=np.array(rP), root_visits=np.array(rV, np.uint64), evaluator_calls=sess.calls,
+                update_plies=np.array(sorted(updates) if updates else [], np.int32),
+                update_json=np.array(__import__("json").dumps({str(k): v for k, v in (updates or {}).items()})))
+
+
+SINGLE_GUMBEL_CASES = [   # name, game, n, m, c_visit, c_scale, seed, salt, max_plies, use_gumbel_noise, updates
+    ("c4_gumbel_single_nonoise", "Connect4", 32, 7, 50.0, 1.0, 31, 4, 42, False, None),
+    ("ttt_gumbel_single_nonoise", "TicTacToe", 16, 4, 50.0, 2.0, 32, 5, 9, False, None),
+    ("c4_gumbel_single_update", "Connect4", 40, 7, 50.0, 1.0, 33, 6, 10, True, {3: dict(m=4, c_scale=0.5), 6: dict(c_visit=20.0)}),
+]
+
+
+TAU_CASES = [   # general tau N^(1/tau) (MCTS.py:606-610) and update_hyperparams of the PUCT constants between moves (MCTS.py:134-168)
+    ("c4_mcts_single_tau", "Connect4", 80, 2.5, 0.5, 41, 12, 42, False, [0.5, 2.0, 0.25, 1.0, 0.8, 3.0, 0.1, 1.5], None),
+    ("ttt_mcts_single_tau", "TicTacToe", 40, 1.25, 1.0, 42, 5, 9, False, [0.7, 0.3, 2.5], None),
+    ("c4_mcts_single_update", "Connect4", 70, 2.5, 0.5, 43, 8, 14, False, None,
+     {2: dict(c_puct_init=1.0), 4: dict(dirichlet_alpha=0.3, dirichlet_epsilon=0.1), 6: dict(c_puct_base=500.0)}),
+]
 
 SINGLE_CASES = [("c4_mcts_single", "Connect4", 60, 2.5, 0.5, 21, 9, 42), ("ttt_mcts_single", "TicTacToe", 30, 1.25, 1.0, 22, 4, 9),
                 # fast_find_win=True (MCTS.py:88,282-283): a node with a winning move keeps only the first one
@@ -166,7 +215,13 @@ def main():
         fx = ref_selfplay_puct(*cfg, opening=opening)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
         print(name, "T =", len(fx["actions"]), "first move", fx["actions"][0], "evals", fx["evaluator_calls"], flush=True)
-    for name, *cfg in SINGLE_CASES:
+    for name, *cfg in SINGLE_GUMBEL_CASES:
+        if only and name not in only:
+            continue
+        fx = ref_single_gumbel(*cfg)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "evals", fx["evaluator_calls"], flush=True)
+    for name, *cfg in SINGLE_CASES + TAU_CASES:
         if only and name not in only:
             continue
         fx = ref_single_tree_puct(*cfg)
