@@ -167,7 +167,7 @@ def _drive_gumbel_fixture(MCTS_Gumbel, fx, lib_path, oracle):
     mcts.close()
 
 
-@pytest.mark.parametrize("name", ["c4_gumbel_single_nonoise", "ttt_gumbel_single_nonoise", "c4_gumbel_single_update"])
+@pytest.mark.parametrize("name", ["c4_gsingle_nonoise", "ttt_gsingle_nonoise", "c4_gsingle_update"])
 def test_mcts_gumbel_class_without_noise_and_with_updates(emu_lib, oracle, name):
     """MCTS_Gumbel(use_gumbel_noise=False) — the class default (MCTS_Gumbel.py:157,592-596) — and update_hyperparams(m, c_visit,
     c_scale) (MCTS_Gumbel.py:186-210), against fixtures recorded from the reference's class."""

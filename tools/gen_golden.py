@@ -166,9 +166,9 @@ def ref_single_gumbel(game, iteration_limit, m, c_visit, c_scale, seed, salt, ma
 
 
 SINGLE_GUMBEL_CASES = [   # name, game, n, m, c_visit, c_scale, seed, salt, max_plies, use_gumbel_noise, updates
-    ("c4_gumbel_single_nonoise", "Connect4", 32, 7, 50.0, 1.0, 31, 4, 42, False, None),
-    ("ttt_gumbel_single_nonoise", "TicTacToe", 16, 4, 50.0, 2.0, 32, 5, 9, False, None),
-    ("c4_gumbel_single_update", "Connect4", 40, 7, 50.0, 1.0, 33, 6, 10, True, {3: dict(m=4, c_scale=0.5), 6: dict(c_visit=20.0)}),
+    ("c4_gsingle_nonoise", "Connect4", 32, 7, 50.0, 1.0, 31, 4, 42, False, None),
+    ("ttt_gsingle_nonoise", "TicTacToe", 16, 4, 50.0, 2.0, 32, 5, 9, False, None),
+    ("c4_gsingle_update", "Connect4", 40, 7, 50.0, 1.0, 33, 6, 10, True, {3: dict(m=4, c_scale=0.5), 6: dict(c_visit=20.0)}),
 ]
 
 
