@@ -61,6 +61,7 @@ def _lib():
         ("H5Pset_create_intermediate_group", C.c_int, [hid_t, C.c_uint]), ("H5Eset_auto2", C.c_int, [hid_t, C.c_void_p, C.c_void_p]),
         ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]), ("H5Fflush", C.c_int, [hid_t, C.c_int]),
         ("H5Lget_name_by_idx", C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, C.c_char_p, C.c_size_t, hid_t]),
+        ("H5Pset", C.c_int, [hid_t, C.c_char_p, C.c_void_p]), ("H5Ldelete", C.c_int, [hid_t, C.c_char_p, hid_t]),
     ]:
         fn = getattr(L, f); fn.restype = res; fn.argtypes = args
     _LIB = L
@@ -82,10 +83,18 @@ _MEM_TYPES = {np.dtype(np.int8): "H5T_NATIVE_INT8_g", np.dtype(np.uint8): "H5T_N
 class H5File:
     """`with H5File(path, "w" | "r" | "r+") as f:`  f.keys(), f.read(name), f.create_dataset(name, data, maxshape), f.write(name, data)"""
 
-    def __init__(self, path, mode="r"):
+    def __init__(self, path, mode="r", clear_status_flags=False):
         L = _lib()
         fapl = L.H5Pcreate(_g("H5P_CLS_FILE_ACCESS_ID_g"))
         L.H5Pset_libver_bounds(fapl, 2, 2)                         # H5F_LIBVER_LATEST, like h5py's libver="latest" (main.py:83)
+        if clear_status_flags:
+            # what `h5clear -s` does: a writer that was killed with the file open leaves the superblock's "open for write" flag
+            # set and libhdf5 then refuses every open; this file-access property makes H5Fopen reset the flag first
+            one = C.c_uint(1)
+            if L.H5Pset(fapl, b"clear_status_flags", C.byref(one)) < 0:
+                L.H5Pclose(fapl)
+                raise OSError("this libhdf5 has no clear_status_flags file-access property")
+        L.H5Eset_auto2(0, None, None)                              # failures are reported through the OSError below, not on stderr
         if mode == "w":
             self.fid = L.H5Fcreate(path.encode(), 2, 0, fapl)      # H5F_ACC_TRUNC
         else:
@@ -114,6 +123,13 @@ class H5File:
 
     def flush(self):
         _lib().H5Fflush(self.fid, 1)                               # H5F_SCOPE_GLOBAL
+
+    def exists(self, name):
+        return _lib().H5Lexists(self.fid, name.encode(), 0) > 0
+
+    def delete(self, name):
+        if _lib().H5Ldelete(self.fid, name.encode(), 0) < 0:
+            raise KeyError(name)
 
     def keys(self):
         L = _lib()

@@ -30,12 +30,14 @@ def reduce_stats(local_counts, world_size, max_fields=()):
     return out
 
 
-def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, seed=0, weights=None, lib_path=None, **kw):
+def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, seed=None, weights=None, lib_path=None, **kw):
     """`run_self_play` on every rank of an initialised torch.distributed job (one process per GPU; backend nccl = RCCL, or gloo):
     the generation's missing games are split over the ranks, each rank plays its share into a private shard file with RNG streams
     keyed by GLOBAL slot (rank r owns slots [r * n_games, (r + 1) * n_games)), then rank 0 appends the shards to
     `folder_path/Self_Play_Data.h5` in rank order.  The only collectives are the broadcast of the number of missing games and the
-    all-reduce of the game_stats counters; no tree, evaluator or replay data crosses GPUs.  Returns the games written by all ranks."""
+    all-reduce of the game_stats counters; no tree, evaluator or replay data crosses GPUs.  Returns the games written by all ranks.
+    `seed=None`: rank 0 draws one from OS entropy (Self_Play.py:221) and every rank uses it; game sequence numbers start at the
+    number of games already in the file, so a resumed generation adds new games even under a fixed seed."""
     import os
     import shutil
     import torch.distributed as dist
@@ -43,13 +45,17 @@ def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, see
     rank, world = dist.get_rank(), dist.get_world_size()
     train_config = dict(configs[1])
     main = ReplayStore(folder_path)
-    left = np.zeros(1, np.int64)
+    left = np.zeros(4, np.int64)                                       # [games missing, games done, seed low 31 bits, seed high 31 bits]
     if rank == 0:
         if not main.exists():
             raise ValueError("Dataset file hasn't been created. Self play depends on that file!")
-        left[0] = max(0, int(train_config["games_per_generation"]) - int(main.game_stats()[2]))
+        done = int(main.game_stats()[2])
+        left[0] = max(0, int(train_config["games_per_generation"]) - done); left[1] = done
+        s0 = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+        left[2] = s0 & 0x7FFFFFFF; left[3] = (s0 >> 31) & 0x7FFFFFFF
     left = reduce_stats(left, world)                                   # ranks > 0 contribute zeros: a broadcast through the one collective
-    games_left = int(left[0])
+    games_left, games_done = int(left[0]), int(left[1])
+    seed = int(left[2]) | (int(left[3]) << 31)
     share = games_left // world + (1 if rank < games_left % world else 0)
     generation = int(str(folder_path).rstrip("/").split("/")[-1])
     shard_dir = os.path.join(folder_path, f".shard{rank}")
@@ -59,7 +65,7 @@ def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, see
     if share > 0:
         run_self_play(game_class, (configs[0], dict(train_config, games_per_generation=share)) + tuple(configs[2:]), shard_dir,
                       n_games=min(n_games, share), seed=seed, weights=weights, device=device, slot_offset=rank * n_games,
-                      lib_path=lib_path, generation=generation, **kw)
+                      lib_path=lib_path, generation=generation, first_game_seq=games_done, **kw)
     local = shard.game_stats().astype(np.int64)
     total = reduce_stats(local, world, max_fields=(0,))                # game_stats: [longest game (max), plies, games, wins -1, draws, wins +1]
     dist.barrier()

@@ -12,6 +12,7 @@ Storage: the reference writes HDF5 through h5py.  h5py is not installed in this 
 importable and otherwise the system libhdf5 through h5io.py (ctypes) — a real `Self_Play_Data.h5` with the same dataset
 names / dtypes / shapes / libver either way.
 """
+import logging
 import os
 
 import numpy as np
@@ -32,7 +33,7 @@ class ReplayStore:
             from . import h5io
             self.backend = "libhdf5" if h5io.available() else "npy"
         self.path = os.path.join(folder_path, "Self_Play_Data.h5" if self.backend != "npy" else "Self_Play_Data.npzdir")
-        self._f = None
+        self._buf, self._buf_bytes, self._in_session = [], 0, False
 
     def _open(self, mode):
         if self.backend == "h5py":
@@ -59,94 +60,137 @@ class ReplayStore:
     def n_datasets(self):
         if self.backend == "npy":
             return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
-        if self._f is not None:
-            return self._f.n_links() - 1
-        with self._open("r") as f:
+        with self._open_checked("r") as f:
             return f.n_links() - 1
 
-    # A generation appends thousands of games: `writing()` keeps ONE handle open for all of them (opening the file and counting its
-    # datasets per game made the writer, not the GPU, the limit: 0.3 s per game growing with the file), flushing every so often so
-    # that an interrupted run keeps what it wrote (the reference re-opens per game under a lock, Self_Play.py:178-208).
-    def writing(self, flush_every=256):
+    # A generation appends thousands of games.  Opening the file and counting its datasets per game made the writer, not the GPU,
+    # the limit (0.3 s per game, growing with the file); holding one handle open for the whole generation (round 1) left the
+    # superblock's write flag set when the process was killed, and the file could not be reopened.  So `writing()` BUFFERS games and
+    # writes them in batches — open, append `flush_every` games, close: the file is open for write only for the milliseconds of a
+    # batch (the reference's exposure is one game's write, Self_Play.py:178-208), and a killed run keeps every batch it completed.
+    def _open_checked(self, mode):
+        """Open for "r" / "r+"; a file left "open for write" by a killed writer (libhdf5 then refuses every open) is repaired first
+        by clearing its status flags — what `h5clear -s` does."""
+        try:
+            return self._open(mode)
+        except OSError:
+            if self.backend != "libhdf5" or not os.path.exists(self.path):
+                raise
+            from .h5io import H5File
+            f = H5File(self.path, "r+", clear_status_flags=True)
+            try:
+                ok = f.n_links() >= 1 and f.read("game_stats").shape == (6,)      # must still be readable, else beyond this repair
+            finally:
+                f.close()
+            if not ok:
+                raise OSError(f"{self.path}: left inconsistent by an interrupted writer")
+            logging.getLogger("grok_alpha_zero_amd").warning("%s was left open by an interrupted writer; status flags cleared", self.path)
+            return self._open(mode)
+
+    def _open_rw(self):
+        return self._open_checked("r+")
+
+    def writing(self, flush_every=64, flush_bytes=64 << 20):
         store = self
 
         class _Session:
             def __enter__(self_inner):
-                if store.backend != "npy":
-                    store._f = store._open("r+")
-                    store._stats = store._f.read("game_stats").astype(np.uint32)
-                    store._k0 = (store._f.n_links() - 1) // 3
-                store._flush_every, store._since_flush = flush_every, 0
+                store._buf, store._buf_bytes = [], 0
+                store._flush_every, store._flush_bytes, store._in_session = flush_every, flush_bytes, True
                 return store
 
             def __exit__(self_inner, *a):
-                if store._f is not None:
-                    store._f.close(); store._f = None
+                try:
+                    store._flush()
+                finally:
+                    store._in_session = False
                 return False
         return _Session()
 
+    def _flush(self):
+        """append the buffered games / dataset triples / stats in ONE open-write-close"""
+        buf, self._buf, self._buf_bytes = self._buf, [], 0
+        if not buf:
+            return
+        if self.backend == "npy":
+            for item in buf:
+                self._write_npy(item)
+            return
+        f = self._open_rw()
+        try:
+            stats = f.read("game_stats").astype(np.uint32)
+            k = (f.n_links() - 1) // 3                                # dataset_name = (len(keys) - 1) // 3 (Self_Play.py:190)
+            if (f.n_links() - 1) % 3:                                 # a writer died inside a triple: drop its incomplete tail
+                for nm in (f"boards_{k}", f"policies_{k}", f"values_{k}"):
+                    if f.exists(nm):
+                        f.delete(nm)
+            for kind, payload in buf:
+                if kind == "stats":
+                    stats = payload.copy()
+                    continue
+                if kind == "game":
+                    boards_aug, policies_aug, values_aug, game_length, n_positions, winner = payload
+                    stats[0] = max(int(stats[0]), game_length); stats[1] += n_positions; stats[2] += 1; stats[winner + 4] += 1
+                    triples = [(boards_aug[i], policies_aug[i], values_aug[i]) for i in range(policies_aug.shape[0])]
+                else:
+                    triples = [payload]
+                for b, p, v in triples:
+                    f.create_dataset(f"boards_{k}", b, maxshape=(None, *b.shape[1:]), dtype=b.dtype)
+                    f.create_dataset(f"policies_{k}", p, maxshape=(None, *p.shape[1:]), dtype=np.float32)
+                    f.create_dataset(f"values_{k}", v, maxshape=(None, *v.shape[1:]), dtype=np.float32)
+                    k += 1
+            f.write("game_stats", stats)                              # last: a batch cut short leaves the count behind the data
+        finally:
+            f.close()
+
+    def _write_npy(self, item):
+        kind, payload = item
+        if kind == "stats":
+            np.save(os.path.join(self.path, "game_stats.npy"), payload)
+            return
+        k = self.n_datasets() // 3
+        if kind == "game":
+            boards_aug, policies_aug, values_aug, game_length, n_positions, winner = payload
+            stats = self.game_stats().astype(np.uint32)
+            stats[0] = max(int(stats[0]), game_length); stats[1] += n_positions; stats[2] += 1; stats[winner + 4] += 1
+            np.save(os.path.join(self.path, "game_stats.npy"), stats)
+            triples = [(boards_aug[i], policies_aug[i], values_aug[i]) for i in range(policies_aug.shape[0])]
+        else:
+            triples = [payload]
+        for b, p, v in triples:
+            np.save(os.path.join(self.path, f"boards_{k}.npy"), b)
+            np.save(os.path.join(self.path, f"policies_{k}.npy"), np.asarray(p, np.float32))
+            np.save(os.path.join(self.path, f"values_{k}.npy"), np.asarray(v, np.float32))
+            k += 1
+
+    def _put(self, item, nbytes):
+        if not getattr(self, "_in_session", False):
+            with self.writing():
+                return self._put(item, nbytes)
+        self._buf.append(item); self._buf_bytes += nbytes
+        n_games = sum(1 for kind, _ in self._buf if kind != "stats")
+        if n_games >= self._flush_every or self._buf_bytes >= self._flush_bytes:
+            self._flush()
+
     def append_game(self, boards_aug, policies_aug, values_aug, game_length, n_positions, winner):
         """One finished game: arrays [n_aug, T, ...] (Self_Play.py:174-208)."""
-        if self.backend != "npy" and self._f is None:
-            with self.writing():
-                return self.append_game(boards_aug, policies_aug, values_aug, game_length, n_positions, winner)
-        if self.backend == "npy":
-            stats = self.game_stats().astype(np.uint32)
-            k0 = self.n_datasets() // 3                               # dataset_name = (len(keys) - 1) // 3
-        else:
-            stats, k0 = self._stats, self._k0
-        stats[0] = max(int(stats[0]), game_length)
-        stats[1] += n_positions
-        stats[2] += 1
-        stats[winner + 4] += 1
-        if self.backend == "npy":
-            np.save(os.path.join(self.path, "game_stats.npy"), stats)
-            for inc in range(policies_aug.shape[0]):
-                np.save(os.path.join(self.path, f"boards_{k0 + inc}.npy"), boards_aug[inc])
-                np.save(os.path.join(self.path, f"policies_{k0 + inc}.npy"), policies_aug[inc].astype(np.float32))
-                np.save(os.path.join(self.path, f"values_{k0 + inc}.npy"), values_aug[inc].astype(np.float32))
-            return
-        f = self._f
-        f.write("game_stats", stats)
-        for inc in range(policies_aug.shape[0]):
-            f.create_dataset(f"boards_{k0 + inc}", boards_aug[inc], maxshape=(None, *boards_aug[inc].shape[1:]), dtype=boards_aug[inc].dtype)
-            f.create_dataset(f"policies_{k0 + inc}", policies_aug[inc], maxshape=(None, *policies_aug[inc].shape[1:]), dtype=np.float32)
-            f.create_dataset(f"values_{k0 + inc}", values_aug[inc], maxshape=(None, *values_aug[inc].shape[1:]), dtype=np.float32)
-        self._k0 = k0 + policies_aug.shape[0]
-        self._since_flush += 1
-        if self._since_flush >= self._flush_every:
-            f.flush(); self._since_flush = 0
+        boards_aug = np.ascontiguousarray(boards_aug); policies_aug = np.ascontiguousarray(policies_aug, np.float32)
+        values_aug = np.ascontiguousarray(values_aug, np.float32)
+        self._put(("game", (boards_aug, policies_aug, values_aug, int(game_length), int(n_positions), int(winner))),
+                  boards_aug.nbytes + policies_aug.nbytes + values_aug.nbytes)
 
     def append_datasets(self, boards, policies, values):
         """one (boards_k, policies_k, values_k) triple as the next k, without touching game_stats (shard merge, parallel.py)"""
-        if self.backend == "npy":
-            k = self.n_datasets() // 3
-            np.save(os.path.join(self.path, f"boards_{k}.npy"), boards); np.save(os.path.join(self.path, f"policies_{k}.npy"), policies)
-            np.save(os.path.join(self.path, f"values_{k}.npy"), values)
-            return
-        if self._f is None:
-            with self.writing():
-                return self.append_datasets(boards, policies, values)
-        k = self._k0
-        self._f.create_dataset(f"boards_{k}", boards, maxshape=(None, *boards.shape[1:]), dtype=boards.dtype)
-        self._f.create_dataset(f"policies_{k}", policies, maxshape=(None, *policies.shape[1:]), dtype=np.float32)
-        self._f.create_dataset(f"values_{k}", values, maxshape=(None, *values.shape[1:]), dtype=np.float32)
-        self._k0 = k + 1
+        boards = np.ascontiguousarray(boards); policies = np.ascontiguousarray(policies, np.float32); values = np.ascontiguousarray(values, np.float32)
+        self._put(("triple", (boards, policies, values)), boards.nbytes + policies.nbytes + values.nbytes)
 
     def set_game_stats(self, stats):
-        stats = np.asarray(stats).astype(np.uint32)
-        if self.backend == "npy":
-            np.save(os.path.join(self.path, "game_stats.npy"), stats)
-            return
-        if self._f is None:
-            with self.writing():
-                return self.set_game_stats(stats)
-        self._f.write("game_stats", stats); self._stats = stats.copy()
+        self._put(("stats", np.asarray(stats).astype(np.uint32)), 24)
 
     def read(self, name):
         if self.backend == "npy":
             return np.load(os.path.join(self.path, name + ".npy"))
-        with self._open("r") as f:
+        with self._open_checked("r") as f:
             return f.read(name)
 
 
@@ -171,6 +215,12 @@ class _H5pyAdapter:
 
     def flush(self):
         self.f.flush()
+
+    def exists(self, name):
+        return name in self.f
+
+    def delete(self, name):
+        del self.f[name]
 
     def close(self):
         self.f.close()
@@ -244,25 +294,44 @@ def record_to_samples(game_class, rec):
 
 
 def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
-                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22, generation=None):
+                  device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22, generation=None,
+                  first_game_seq=None, allow_synthetic=False):
     """Generate `games_per_generation - game_stats[2]` self-play games into `folder_path` (Self_Play.py:259-272).
     `configs` = (build_config, train_config[, optimizer_config]).  `weights` = dict from net.export_engine_weights()
     (generation > 0); generation 0 (folder name "0") plays with the synthetic evaluator like the reference's
-    session=None dummy (Self_Play.py:40, MCTS.py:237-241)."""
+    session=None dummy (Self_Play.py:40, MCTS.py:237-241).
+
+    Which games: the reference starts exactly the missing games and runs every one of them to its end (Self_Play.py:346-408).
+    The engine restarts slots on device, so the admitted set is fixed up front the same way: slot g plays its k-th game iff
+    k * G + g < games_left (`games_budget`), then halts; every admitted game is written, whatever order they finish in.  (Keeping
+    the first games to FINISH instead would favour short games.)  RNG streams are keyed by (seed, slot, game_seq) and game_seq
+    starts at `first_game_seq` (default: the games already in the file), so a resumed generation never replays a game even
+    with the same seed."""
     build_config, train_config = configs[0], configs[1]
     store = ReplayStore(folder_path)
     if not store.exists():
         raise ValueError("Dataset file hasn't been created. Self play depends on that file!")     # Self_Play.py:264-265
-    games_left = int(train_config["games_per_generation"] - store.game_stats()[2])
+    games_done = int(store.game_stats()[2])
+    games_left = int(train_config["games_per_generation"] - games_done)
     if games_left <= 0:
         return 0
     if generation is None:
         generation = int(str(folder_path).rstrip("/").split("/")[-1])                 # Self_Play.py:274
     name = getattr(game_class, "ENGINE_NAME", game_class.__name__)
+    if generation > 0 and weights is None and not allow_synthetic:
+        # the reference would fail loading model.onnx here; silently writing hash-evaluator games as training data is worse
+        raise ValueError(f"generation {generation} needs network weights (weights=net.export_engine_weights()); "
+                         "pass allow_synthetic=True to play with the synthetic evaluator on purpose")
     use_net = generation > 0 and weights is not None
+    if use_net and name == "Connect4" and int(build_config.get("num_filters", 128)) != 128:
+        from .engine import EngineError
+        raise EngineError("the Connect4 trunk kernels are built for num_filters = 128 (Connect4/Build_Model.py's default); "
+                          f"num_filters = {build_config.get('num_filters')} would need the block-0 projection path")
     G = min(n_games, games_left)
     if seed is None:
         seed = int.from_bytes(os.urandom(8), "little")                 # np.random.seed() from OS entropy (Self_Play.py:221)
+    if first_game_seq is None:
+        first_game_seq = games_done
     gumbel = bool(train_config.get("use_gumbel"))
     # PUCT runs int(1.5 * limit) iterations per move (Self_Play.py:99), Gumbel runs `limit` (Self_Play.py:110-112)
     iters = int(train_config["MCTS_iteration_limit"]) if gumbel else int(train_config["MCTS_iteration_limit"] * 1.5)
@@ -280,26 +349,29 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                          evaluator=EVAL_RESNET if use_net else EVAL_HASH, hash_salt=hash_salt,
                          net_blocks=build_config.get("num_resnet_layers", 0) if use_net else 0,
                          net_filters=build_config.get("num_filters", 128), ring_capacity=max(4 * G, 64), lib_path=lib_path,
-                         eval_cache_log2=eval_cache_log2)    # on-device Session_Cache (Self_Play.py:234-236): same games, fewer waves
+                         eval_cache_log2=eval_cache_log2,    # on-device Session_Cache (Self_Play.py:234-236): same games, fewer waves
+                         games_budget=games_left, first_game_seq=first_game_seq)
+    logging.getLogger("grok_alpha_zero_amd").info("run_self_play: generation %d, %d games on %d slots, evaluator = %s, game_seq from %d",
+                                                  generation, games_left, G, "ResNet (HIP)" if use_net else "synthetic hash evaluator", first_game_seq)
     if use_net:
         eng.load_weights(weights)
     written = 0
-    session = store.writing()
-    session.__enter__()
     try:
-        eng.run_waves(64)
-        while written < games_left:
-            recs = eng.drain_finished()             # waits for the launches queued so far
-            eng.run_waves(64)                       # queue the next ones right away: the GPU works while the host converts and writes
-            for rec in recs:
-                if written >= games_left:
-                    break
-                aug_b, aug_p, aug_v, length = record_to_samples(game_class, rec)
-                store.append_game(aug_b, aug_p, aug_v, length, rec["T"], rec["winner"])
-                written += 1
-                if progress:
-                    progress(written, games_left)
+        with store.writing():
+            eng.run_waves(64)
+            idle = 0
+            while written < games_left:
+                recs = eng.drain_finished()             # waits for the launches queued so far
+                eng.run_waves(64)                       # queue the next ones right away: the GPU works while the host converts and writes
+                for rec in recs:                        # every record is one of the admitted games (games_budget)
+                    aug_b, aug_p, aug_v, length = record_to_samples(game_class, rec)
+                    store.append_game(aug_b, aug_p, aug_v, length, rec["T"], rec["winner"])
+                    written += 1
+                    if progress:
+                        progress(written, games_left)
+                idle = 0 if recs else idle + 1
+                if idle > 100000:
+                    raise RuntimeError("self-play made no progress")
     finally:
-        session.__exit__(None, None, None)
         eng.close()
     return written

@@ -195,7 +195,8 @@ def test_orchestrator_run_loop_and_resume(tmp_path):
     trained = []
     log = []
     stats = Run(GAMES["TicTacToe"], ({}, train), train_fn=lambda g, src, dst: trained.append((g, os.path.isdir(dst))),
-                weights_fn=lambda folder: None, root=root, n_games=2, seed=5, lib_path=emu, out=log.append)
+                weights_fn=lambda folder: None, root=root, n_games=2, seed=5, lib_path=emu, out=log.append,
+                self_play_kwargs=dict(allow_synthetic=True))
     assert [s["generation"] for s in stats] == [0, 1, 2]
     assert stats[0]["played_now"] == 2 and stats[1]["played_now"] == 4            # generation 0 resumed from game_stats[2] = 2
     assert trained == [(0, True), (1, True), (2, True)]
@@ -206,7 +207,10 @@ def test_orchestrator_run_loop_and_resume(tmp_path):
     assert any("Generation: 2 / 2" in l for l in log) and log[-1] == "-----------Training Done!-----------"
     # starting again resumes at the highest generation folder and has nothing left to play in it once its file exists
     make_dataset_file(os.path.join(root, "3"))
-    again = Run(GAMES["TicTacToe"], ({}, dict(train, total_generations=4)), root=root, n_games=2, seed=9, lib_path=emu, out=lambda *_: None)
+    with pytest.raises(ValueError, match="needs network weights"):       # generation 3 without weights: refused, not silently synthetic
+        Run(GAMES["TicTacToe"], ({}, dict(train, total_generations=4)), root=root, n_games=2, seed=9, lib_path=emu, out=lambda *_: None)
+    again = Run(GAMES["TicTacToe"], ({}, dict(train, total_generations=4)), root=root, n_games=2, seed=9, lib_path=emu, out=lambda *_: None,
+                self_play_kwargs=dict(allow_synthetic=True))
     assert [s["generation"] for s in again] == [3] and again[0]["played_now"] == 4
 
 
@@ -312,13 +316,149 @@ def test_sharded_self_play_two_ranks_gloo(tmp_path, oracle):
     gs = store.game_stats()
     assert gs[2] == 9 and gs[3] + gs[4] + gs[5] == 9 and store.n_datasets() == 9 * 8 * 3
     assert not any(n.startswith(".shard") for n in os.listdir(folder))
-    # shard games: rank 0 plays 4 (slots 0-2 first), rank 1 plays 3 (slots 3-5); each is the oracle's game of that global slot
+    # shard games: rank 0 plays 4 (slots 0-2 first), rank 1 plays 3 (slots 3-5); each is the oracle's game of that global slot;
+    # game sequence numbers start at the 2 games the file already held (resume never replays a stream)
     lengths = {}
     for slot in range(6):
-        for seq in range(3):
+        for seq in range(2, 4):
             o = oracle.selfplay_game("TicTacToe", 21, 9, 2, 1, 1.25, 1.0, 17, slot, seq, hash_salt=6)
             lengths[(slot, seq)] = (o["T"], o["states"][:o["T"]])
     merged = [store.read(f"boards_{k * 8}") for k in range(2, 9)]
+    want = {(s_, q) for s_ in range(6) for q in range(2, 4) if (q - 2) * 3 + (s_ % 3) < (4 if s_ < 3 else 3)}    # each rank's admitted set
+    assert len(want) == 7
+    got = set()
     for b in merged:
-        assert any(b.shape[0] == T and np.array_equal(b, st) for T, st in lengths.values())
+        hits = [key for key, (T, st) in lengths.items() if b.shape[0] == T and np.array_equal(b, st)]
+        assert hits, "a merged game is not one of the oracle's"
+        got.update(h for h in hits if h in want)
+    assert got == want
     assert sum(b.shape[0] for b in merged) + sum(store.read(f"boards_{k * 8}").shape[0] for k in range(2)) == gs[1]
+
+
+def _emu():
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    return os.path.join(emu_dir, "libgaz_emu.so")
+
+
+def _written_games(store, n_aug):
+    n = store.n_datasets() // 3 // n_aug
+    return [store.read(f"boards_{k * n_aug}") for k in range(n)]
+
+
+def test_run_self_play_writes_the_games_started_not_the_first_to_finish(tmp_path, oracle):
+    """a generation is the first N games STARTED, each run to its end (Self_Play.py:346-408).  With 5 slots and 12
+    games the admitted set is {(slot g, k-th game): k * 5 + g < 12}; every one of them is in the file — including the long ones a
+    "first 12 to finish" rule would drop — and nothing else is."""
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu = _emu()
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    train = dict(games_per_generation=12, MCTS_iteration_limit=20, max_actions=42, num_explore_actions_first=8,
+                 num_explore_actions_second=7, c_puct_init=2.5, dirichlet_alpha=0.5, use_gumbel=False)
+    assert run_self_play(GAMES["Connect4"], ({}, train), folder, n_games=5, seed=7, hash_salt=3, lib_path=emu, eval_cache_log2=0) == 12
+    want = {}
+    for g in range(5):
+        for k in range(3):
+            if k * 5 + g < 12:
+                o = oracle.selfplay_game("Connect4", 30, 42, 8, 7, 2.5, 0.5, 7, g, k, hash_salt=3)
+                want[(g, k)] = (o["states"][:o["T"]], o["winner"])
+    assert len(want) == 12
+    games = _written_games(store, 2)
+    assert len(games) == 12
+    matched = set()
+    for b in games:
+        hit = [key for key, (st, _) in want.items() if st.shape == b.shape and np.array_equal(st, b)]
+        assert len(hit) == 1, "a written game is not (exactly one of) the admitted games"
+        matched.add(hit[0])
+    assert matched == set(want)
+    gs = store.game_stats()
+    winners = [w for _, w in want.values()]
+    assert gs[2] == 12 and gs[1] == sum(st.shape[0] for st, _ in want.values()) and gs[0] == max(st.shape[0] for st, _ in want.values())
+    assert [gs[3], gs[4], gs[5]] == [winners.count(-1), winners.count(0), winners.count(1)]
+
+
+def test_resumed_generation_never_replays_a_game(tmp_path, oracle):
+    """RNG streams are keyed by (seed, slot, game_seq); a resumed generation continues game_seq at the number of
+    games already in the file, so the same seed yields NEW games (round 1 replayed game_seq 0 bit for bit)."""
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu = _emu()
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    train = dict(games_per_generation=2, MCTS_iteration_limit=14, max_actions=9, num_explore_actions_first=2, num_explore_actions_second=1,
+                 c_puct_init=1.25, dirichlet_alpha=1.0, use_gumbel=False)
+    assert run_self_play(GAMES["TicTacToe"], ({}, train), folder, n_games=2, seed=3, lib_path=emu) == 2
+    assert run_self_play(GAMES["TicTacToe"], ({}, dict(train, games_per_generation=4)), folder, n_games=2, seed=3, lib_path=emu) == 2
+    games = _written_games(store, 8)
+    pol = [store.read(f"policies_{k * 8}") for k in range(4)]
+    keys = [(b.tobytes(), p.tobytes()) for b, p in zip(games, pol)]
+    assert len(set(keys)) == 4, "the resumed run replayed a game of the first run"
+    # and they are the oracle's games of sequence numbers 0 (first run) and 2 (resume: 2 games were in the file)
+    for seq, ks in ((0, (0, 1)), (2, (2, 3))):
+        exp = [oracle.selfplay_game("TicTacToe", 21, 9, 2, 1, 1.25, 1.0, 3, g, seq)["states"] for g in range(2)]
+        for k in ks:
+            assert any(e.shape[0] == games[k].shape[0] and np.array_equal(e[:games[k].shape[0]], games[k]) for e in exp)
+
+
+_KILL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from grok_alpha_zero_amd.self_play import ReplayStore
+store = ReplayStore(sys.argv[2])
+mode = sys.argv[3]
+b = np.zeros((2, 5, 6, 7, 4), np.int8); p = np.full((2, 5, 7), 1 / 7, np.float32); v = np.zeros((2, 5, 1), np.float32)
+if mode == "between_batches":
+    with store.writing(flush_every=1):
+        store.append_game(b, p, v, 5, 5, -1)
+        store.append_game(b + 1, p, v, 5, 5, 1)
+        store.append_game(b + 2, p, v, 5, 5, 0)      # buffered + flushed one by one; die right after
+        os._exit(9)
+else:                                                 # die with the HDF5 handle open for write
+    f = store._open_rw()
+    f.create_dataset("boards_0", b[0], maxshape=(None, 6, 7, 4), dtype=np.int8); f.flush()
+    os._exit(9)
+"""
+
+
+@pytest.mark.parametrize("mode", ["between_batches", "handle_open"])
+def test_replay_file_survives_a_hard_kill(tmp_path, mode):
+    """a SIGKILL / OOM kill / box reset must not leave Self_Play_Data.h5 unopenable.  The writer now opens the
+    file only for the duration of a batch; a kill between batches leaves a clean file with every completed batch, and a kill with
+    the handle open (superblock write flag left set) is repaired on the next open (what `h5clear -s` does)."""
+    from grok_alpha_zero_amd.self_play import ReplayStore
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    if store.backend == "npy":
+        pytest.skip("no HDF5 library")
+    script = tmp_path / "kill_worker.py"; script.write_text(_KILL_WORKER)
+    rc = subprocess.call([sys.executable, str(script), ROOT, folder, mode])
+    assert rc == 9
+    gs = store.game_stats()                        # reading comes first in run_self_play (games_left): it must work after the kill too
+    if mode == "between_batches":
+        assert gs[2] == 3 and store.n_datasets() == 3 * 2 * 3 and [gs[3], gs[4], gs[5]] == [1, 1, 1]
+    # resuming works either way: one more game goes in and the file stays readable
+    b = np.zeros((2, 4, 6, 7, 4), np.int8); p = np.full((2, 4, 7), 1 / 7, np.float32); v = np.zeros((2, 4, 1), np.float32)
+    store.append_game(b, p, v, 4, 4, 0)
+    gs = store.game_stats()
+    assert gs[2] == (4 if mode == "between_batches" else 1)
+    k = store.n_datasets() // 3 - 1
+    assert store.read(f"boards_{k}").shape == (4, 6, 7, 4)
+
+
+def test_run_self_play_refuses_unsupported_requests(tmp_path):
+    """generation > 0 without weights does not silently fall back to the synthetic evaluator; a Connect4
+    num_filters the trunk kernels are not built for is rejected with a clear error instead of a bare assert."""
+    from grok_alpha_zero_amd.engine import EngineError
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    emu = _emu()
+    folder = str(tmp_path / "Grok_Zero_Train" / "1")
+    ReplayStore(folder).create()
+    train = dict(games_per_generation=2, MCTS_iteration_limit=8, max_actions=42, num_explore_actions_first=2, num_explore_actions_second=1,
+                 c_puct_init=2.5, dirichlet_alpha=0.5, use_gumbel=False)
+    with pytest.raises(ValueError, match="needs network weights"):
+        run_self_play(GAMES["Connect4"], ({}, train), folder, n_games=2, seed=1, lib_path=emu)
+    with pytest.raises(EngineError, match="num_filters"):
+        run_self_play(GAMES["Connect4"], (dict(num_resnet_layers=2, num_filters=64), train), folder, n_games=2, seed=1, lib_path=emu,
+                      weights={"dummy": np.zeros(1, np.float32)})
+    assert run_self_play(GAMES["Connect4"], ({}, train), folder, n_games=2, seed=1, lib_path=emu, allow_synthetic=True) == 2
