@@ -6,11 +6,20 @@ one tree-kernel launch + one evaluator forward over all G leaves); games restart
 stays constant.  value = plies played by all ranks (delta game_stats[1]) / wall time of the K timed steps
 (barrier + synchronize on both sides, max over ranks).  Inputs are device resident: nothing crosses PCIe in the
 timed region except the per-step stats read-back after it ends.
+
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` (no RANK in the environment) is the LAUNCHER: it touches no
+GPU, checks that N devices exist, starts N fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+set, the fan-out of Self_Play.py:346-363), forwards rank 0's JSON line and fails if any rank fails.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already exist and each runs the bench body.
+Games shard by global slot (rank r owns slots [r G, (r + 1) G)); the only collective is the all-reduce of the counters.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -22,7 +31,7 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_
 PEAK_HBM_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)     # 8 x 400 waves = ~20 plies of every game at 200 sims/move (measure >= 20 plies per game)
@@ -37,34 +46,155 @@ def parse():
     ap.add_argument("--max-tree-sims", type=int, default=0, help="evaluation-free simulations per game per wave (0 = library default)")
     ap.add_argument("--cache-leg", type=int, default=-1, help="log2 entries of the evaluation cache used by the extra with_eval_cache leg (0 = skip the leg; default 24, Gomoku 0: 5 %% hits there)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the on-device evaluation cache (SURVEY 8f rank 3); 0 = off (the headline number is measured with it off: every request goes through the evaluator)")
+    ap.add_argument("--ref-convention-leg", type=int, default=-1, help="1: extra leg at int(1.5 * sims) simulations per move, what Self_Play passes for MCTS_iteration_limit = sims (Self_Play.py:99); default on for the connect4 config at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
-    return ap.parse_args()
+    ap.add_argument("--emu-lib", default="", help="TEST HOOK (tests/test_bench_launcher.py): run the bench body on the one-lane CPU emulation build of the "
+                                                  "device code over gloo; never a measurement")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def visible_gpus():
+    """Number of GPUs, WITHOUT initialising the runtime in this process (device_count() does not on this image): the launcher must
+    stay GPU-free — a process that has touched the GPU may not be replaced or forked into ranks."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch(args, argv):
+    """Parent of `python bench.py --gpus N`: N fresh children, one per GPU (Self_Play.py:346-363 starts one process per worker)."""
+    n = args.gpus
+    have = n if args.emu_lib else visible_gpus()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but {have} GPU(s) are visible: refusing to report a {n}-GPU number from fewer devices",
+              file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode().splitlines()), daemon=True)
+    reader.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()                          # exact PIDs we started, never a pattern
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    lines = [ln for ln in out0 if ln.startswith("{")]
+    if rc == 0 and not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr, flush=True)
+        rc = 3
+    if rc == 0:
+        res = json.loads(lines[-1])
+        if res.get("n_gpus") != n:
+            print(f"bench.py: rank 0 reported n_gpus = {res.get('n_gpus')}, expected {n}", file=sys.stderr, flush=True)
+            return 4
+        print(lines[-1], flush=True)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args, net):
-    """The oracle (C restatement of the reference's Self_Play.play, one game at a time, one evaluator call per leaf —
-    the reference's execution model) on the host cores of this box, evaluator = the same network in PyTorch fp32 on
-    CPU.  Bounded sample of the same workload (Connect4, same sims/move, same net)."""
+    """The reference's execution model on this box's host cores: one game per worker, every leaf a blocking
+    request to ONE inference server that batches whatever the workers have posted (Client_Server.py:162-217) — here W = all host
+    cores worker threads, each playing oracle games (the C restatement of Self_Play.play; ctypes releases the GIL while it
+    searches), and a server thread running the same network in PyTorch fp32 on the same cores.  Whole games, restarted as they
+    finish; runs for --cpu-baseline-seconds and counts the plies completed in that window."""
+    import queue
     import torch
     from oracle import gaz_oracle as O
     O.build()
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))
+    W = cores
     torch.set_num_threads(cores)
+    reqs = queue.Queue()
+    stop = threading.Event()
+    A = 7
+    uniform = (np.full(A, 1.0 / A, np.float32), 0.0)
+    stat = dict(batches=0, evals=0)
 
-    def ev(state):
-        with torch.no_grad():
-            p, v = net(torch.from_numpy(state[None].copy()))
-        return p[0].numpy(), float(v[0, 0])
-    t0 = time.time(); positions = 0; games = 0; evals = 0
-    while time.time() - t0 < args.cpu_baseline_seconds:
-        # one bounded game: cap plies so a single call stays within the sample budget
-        r = O.selfplay_game("Connect4", args.sims, 3, 8, 7, 2.5, 0.5, 1234, games, 0, evaluator=ev)
-        positions += r["T"]; games += 1; evals += r["total_evals"]
-    dt = time.time() - t0
+    def server():
+        while True:
+            first = reqs.get()
+            if first is None:
+                return
+            batch = [first]
+            t_end = time.perf_counter() + 3e-4                     # let the other workers' requests of this round arrive
+            while len(batch) < W:
+                try:
+                    batch.append(reqs.get(timeout=max(0.0, t_end - time.perf_counter())))
+                except queue.Empty:
+                    break
+                if batch[-1] is None:
+                    batch.pop(); reqs.put(None); break
+            if stop.is_set():
+                for st, box, ev in batch:
+                    box.append(uniform); ev.set()
+                continue
+            x = torch.from_numpy(np.stack([b[0] for b in batch]))
+            with torch.no_grad():
+                p, v = net(x)
+            p = p.numpy(); v = v.numpy().reshape(-1)
+            stat["batches"] += 1; stat["evals"] += len(batch)
+            for i, (st, box, ev) in enumerate(batch):
+                box.append((p[i], float(v[i]))); ev.set()
+
+    workers = [dict(done=0, games=0, live={}) for _ in range(W)]
+
+    def worker(w):
+        def ev(state):
+            if stop.is_set():
+                return uniform                                     # drain: the window is over, finish the game without the network
+            box, e = [], threading.Event()
+            reqs.put((state.copy(), box, e)); e.wait()
+            return box[0]
+        k = 0
+        while not stop.is_set():
+            r = O.selfplay_game("Connect4", args.sims, 42, 8, 7, 2.5, 0.5, 1234, w, k, evaluator=ev, live=workers[w]["live"])
+            if not stop.is_set():
+                workers[w]["done"] += r["T"]; workers[w]["games"] += 1
+            k += 1
+
+    srv = threading.Thread(target=server, daemon=True); srv.start()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(W)]
+    for t in th:
+        t.start()
+    time.sleep(args.cpu_baseline_seconds)
+    # plies completed inside the window: finished games + the games in progress (rec.T is updated after every ply)
+    positions = sum(wk["done"] + (int(wk["live"]["rec"].T) if "rec" in wk["live"] else 0) for wk in workers)
+    dt = time.perf_counter() - t0
+    stop.set()
+    for t in th:
+        t.join(timeout=120)
+    reqs.put(None); srv.join(timeout=10)
+    games = sum(wk["games"] for wk in workers)
     return dict(value=positions / dt, unit="positions/s", cores=cores, kind="port",
-                sample=f"{games} games cut at 3 plies = {positions} positions, {evals} evaluator calls in {dt:.1f}s; "
-                       f"oracle/ C restatement, sequential games, batch-1 PyTorch fp32 CPU evaluator ({cores} threads)")
+                sample=f"{W} concurrent whole games (one oracle game per host core, restarted as they finish) for {dt:.1f}s = {positions} plies, "
+                       f"{games} games finished; {stat['evals']} evaluator requests served in {stat['batches']} batches (mean batch "
+                       f"{stat['evals'] / max(stat['batches'], 1):.1f}) by one PyTorch fp32 CPU server on the same {cores} cores — the reference's "
+                       f"worker + inference-server model (Self_Play.py:346-363, Client_Server.py:162-217) with oracle/ as the search",
+                evals_per_s=stat["evals"] / dt, mean_batch=stat["evals"] / max(stat["batches"], 1))
 
 
 CONFIGS = {   # game, games/GPU, sims/move, blocks, max_actions, explore first/second, c_puct, alpha, search, m
@@ -75,7 +205,10 @@ CONFIGS = {   # game, games/GPU, sims/move, blocks, max_actions, explore first/s
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args, argv))
     game, dG, dS, dB, max_actions, ef, es, cpuct, alpha, search, gm = CONFIGS[args.config]
     args.games = args.games or dG; args.sims = args.sims or dS; args.blocks = args.blocks or dB
     if args.cache_leg < 0:
@@ -84,126 +217,154 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: the launcher and the flag disagree", file=sys.stderr, flush=True)
+        sys.exit(2)
+    emu = bool(args.emu_lib)
+    if not emu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+        assert local < torch.cuda.device_count(), f"rank {rank}: no GPU {local} on this node"
+        torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local) if torch.cuda.is_available() else None)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    torch.cuda.set_device(local)
+        dist.init_process_group("gloo" if emu else "nccl", rank=rank, world_size=world,
+                                device_id=None if emu else torch.device("cuda", local))
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET, EVAL_HASH, SEARCH_GUMBEL, SEARCH_PUCT
     from grok_alpha_zero_amd.net import NETS, flops_per_position
     from grok_alpha_zero_amd.parallel import reduce_stats
 
     G = args.games
     gumbel = search == "gumbel"
-    net = NETS[game](args.blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval()
-    eng = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
-                         evaluator=EVAL_RESNET if args.evaluator == "resnet" else EVAL_HASH, net_blocks=args.blocks,
-                         hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
-                         c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims, eval_cache_log2=args.eval_cache)
-    if args.evaluator == "resnet":
-        eng.load_weights(net.export_engine_weights())
+    use_net = args.evaluator == "resnet"
+    net = NETS[game](args.blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval() if (use_net or not args.no_cpu_baseline) else None
+    weights = net.export_engine_weights() if use_net else None
 
-    def barrier():
-        eng.synchronize(); torch.cuda.synchronize()
+    def make_engine(sims, cache_log2):
+        e = SelfPlayEngine(game, G, sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=0 if emu else local,
+                           evaluator=EVAL_RESNET if use_net else EVAL_HASH, net_blocks=args.blocks if use_net else 0,
+                           hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
+                           c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims,
+                           eval_cache_log2=cache_log2, lib_path=args.emu_lib or None)
+        if use_net:
+            e.load_weights(weights)
+        return e
+
+    def barrier(e):
+        e.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
 
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"engine ready: {G} games, {args.sims} sims/move, evaluator={args.evaluator}")
-    for i in range(args.warmup):
-        eng.run_waves(args.waves_per_step)
-        eng.synchronize()
-        log(f"warmup step {i} done")
-    barrier()
-    s0 = eng.stats()
-    eng.timing_reset(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run_waves(args.waves_per_step)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_run(e, with_timing):
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; -> (seconds (max over ranks), counter deltas)"""
+        for i in range(args.warmup):
+            e.run_waves(args.waves_per_step); e.synchronize()
+        barrier(e)
+        s0 = e.stats()
+        if with_timing:
+            e.timing_reset(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e.run_waves(args.waves_per_step)
+        barrier(e)
+        dt = time.perf_counter() - t0
+        s1 = e.stats()
+        d = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]), s1["evals"] - s0["evals"],
+                      s1["sims"] - s0["sims"], s1["cache_hits"] - s0["cache_hits"]], np.int64)
+        return max_over_ranks(dt), d
+
+    eng = make_engine(args.sims, args.eval_cache)
+    log(f"engine ready: {world} rank(s) x {G} games, {args.sims} sims/move, evaluator={args.evaluator}")
+    dt, delta = timed_run(eng, True)
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
-    s1 = eng.stats()
     tm = eng.timing()
-    eng_kernel = eng.dominant_kernel()
+    kname, kflops = eng.dominant_kernel()
     eng.timing_reset(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
-    delta = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]),
-                      s1["evals"] - s0["evals"], s1["sims"] - s0["sims"], s1["cache_hits"] - s0["cache_hits"]], np.int64)
     total = reduce_stats(delta, world)                      # the one collective of the path: counters only
     positions, games, evals, sims, hits = (int(x) for x in total)
+    per_rank = np.zeros(world, np.int64); per_rank[rank] = delta[0]
+    per_rank = reduce_stats(per_rank, world)
+    eng.close()
 
+    out = None
     if rank == 0:
-        HWc = net.H * net.W
-        fl = flops_per_position(args.blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * args.blocks)
+        HWc = net.H * net.W if net is not None else 0
+        fl = (flops_per_position(args.blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * args.blocks)) if net is not None else dict(total=0.0)
         roof = None
-        kname, kflops = eng_kernel
-        if args.evaluator == "resnet" and tm["n_dominant"] > 0 and kflops > 0:
+        if use_net and tm["n_dominant"] > 0 and kflops > 0:
             avg_ms = tm["ms_dominant"] / tm["n_dominant"]
             ach = kflops / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            # per-launch HBM bytes of the dominant kernel from the PMC passes (tools/pmc_traffic.py; measured on this workload only)
+            traffic, traffic_src = None, None
+            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this very command
+            # (tools/profile_round.sh -> tools/pmc_traffic.py); a PMC pass cannot run inside the timed process, so the figure is
+            # profile-derived and labelled as such.  Only quoted for the workload it was collected on.
             import glob
             for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
                 tj = json.load(open(tf))
                 if args.config == "connect4" and G == 4096 and tj.get("kernel_tag") and kname.startswith(tj["kernel_tag"]):
-                    traffic = tj.get("bytes_per_launch")
+                    traffic, traffic_src = tj.get("bytes_per_launch"), os.path.relpath(tf, ROOT)
             roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
+                        traffic_source=(f"{traffic_src}: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this command, "
+                                        "not measured in this run") if traffic_src else None,
                         kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
         label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[args.config]
         out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
                    value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="bf16", data="synthetic",
+                   dtype="bf16", data="synthetic" if not emu else "synthetic — EMULATION BUILD ON CPU (launcher test), NOT A MEASUREMENT",
                    config=dict(workload=f"{label}, {G} concurrent games/GPU, {args.sims} sims/move (MCTS.run iteration_limit), "
                                         f"{args.blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
                                games_per_gpu=G, sims_per_move=args.sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
-                               parallelism=f"games sharded x{world}, counters all-reduced"),
-                   detail=dict(positions=positions, games_finished=games, evaluator_calls=evals, simulations=sims,
+                               parallelism=f"games sharded x{world} (rank r owns global slots [r G, (r + 1) G)), counters all-reduced"),
+                   detail=dict(positions=positions, positions_per_rank=[int(x) for x in per_rank], games_finished=games,
+                               evaluator_calls=evals, simulations=sims,
                                evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=sims / dt,
                                eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
                                eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
                                ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
                                ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1)),
                    roofline=roof)
-        if not args.no_cpu_baseline and world == 1 and args.config == "connect4":
-            out["cpu_baseline"] = cpu_baseline(args, net)
-    eng.close()
-    # ---- extra leg (not the headline): the same workload with the on-device evaluation cache (the reference's
-    # Connect4 config runs its Session_Cache too, max_cache_depth = 2).  Search results are bit-identical; requests that repeat a
-    # state already evaluated are answered from HBM inside the tree kernel and cost no wave.
-    if args.cache_leg and args.eval_cache == 0 and args.evaluator == "resnet":
-        eng2 = SelfPlayEngine(game, G, args.sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=local,
-                              evaluator=EVAL_RESNET, net_blocks=args.blocks, hash_salt=7, ring_capacity=0,
-                              search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm, c_visit=50.0, c_scale=1.0,
-                              policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims, eval_cache_log2=args.cache_leg)
-        eng2.load_weights(net.export_engine_weights())
-        for _ in range(args.warmup):
-            eng2.run_waves(args.waves_per_step)
-        eng2.synchronize(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        c0 = eng2.stats(); t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng2.run_waves(args.waves_per_step)
-        eng2.synchronize(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt2 = time.perf_counter() - t0
-        c1 = eng2.stats()
-        if world > 1:
-            tt = torch.tensor([dt2], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt2 = float(tt.item())
-        d2 = reduce_stats(np.array([int(c1["plies"] - c0["plies"]), c1["evals"] - c0["evals"], c1["cache_hits"] - c0["cache_hits"]], np.int64), world)
-        eng2.close()
+
+    # ---- extra legs (never the headline value) -------------------------------------------------------------------------
+    # (1) the same workload with the on-device evaluation cache (SURVEY 8f rank 3; the reference's Connect4 config runs its
+    #     Session_Cache too).  Search results are bit-identical; repeated states are answered from HBM inside the tree kernel.
+    if args.cache_leg and args.eval_cache == 0 and use_net:
+        e2 = make_engine(args.sims, args.cache_leg)
+        dt2, d2 = timed_run(e2, False)
+        t2 = reduce_stats(d2, world)
+        e2.close()
         if rank == 0:
-            out["with_eval_cache"] = dict(value=int(d2[0]) / dt2, unit="positions/s", entries_log2=args.cache_leg,
-                                          hit_fraction=int(d2[2]) / max(int(d2[1]), 1), ms_per_step=dt2 / args.steps * 1e3,
+            out["with_eval_cache"] = dict(value=int(t2[0]) / dt2, unit="positions/s", entries_log2=args.cache_leg,
+                                          hit_fraction=int(t2[4]) / max(int(t2[2]), 1), ms_per_step=dt2 / args.steps * 1e3,
                                           note="same search results bit for bit; NOT the headline value")
+    # (2) the reference's own convention: Self_Play passes int(1.5 * MCTS_iteration_limit) to MCTS.run (Self_Play.py:99), so a
+    #     config that says "200" runs 300 simulations per move there (SURVEY 8d second line).
+    ref_leg = args.ref_convention_leg if args.ref_convention_leg >= 0 else int(args.config == "connect4" and world == 1 and not gumbel)
+    if ref_leg and not gumbel:
+        sims3 = int(args.sims * 1.5)
+        e3 = make_engine(sims3, args.eval_cache)
+        dt3, d3 = timed_run(e3, False)
+        t3 = reduce_stats(d3, world)
+        e3.close()
+        if rank == 0:
+            out["reference_convention"] = dict(value=int(t3[0]) / dt3, unit="positions/s", sims_per_move=sims3,
+                                               evals_per_position=int(t3[2]) / max(int(t3[0]), 1), ms_per_step=dt3 / args.steps * 1e3,
+                                               note=f"MCTS_iteration_limit = {args.sims} as Self_Play runs it: int(1.5 * limit) = {sims3} simulations per "
+                                                    "move (Self_Play.py:99); NOT the headline value")
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.config == "connect4" and not emu:
+        out["cpu_baseline"] = cpu_baseline(args, net)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -664,8 +664,13 @@ struct ResNetEvaluator : Evaluator {
     const char* dominant_kernel(int n, double* flops) override {
         const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
         *flops = fused ? 2 * conv : conv;
-        if (fused && trunk) { *flops = 2 * conv * blocks; return trunk_whole ? "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"
-                               : "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16, activations resident in LDS)"; }
+        if (fused && trunk) {
+            *flops = 2 * conv * blocks;
+            if (trunk_whole) return trunk_m16 ? "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS)"
+                                              : "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on v_mfma_f32_32x32x16_bf16, activations resident in LDS)";
+            return trunk_m16 ? "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS)"
+                             : "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_32x32x16_bf16, activations resident in LDS)";
+        }
         return fused ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                      : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }
@@ -953,7 +958,8 @@ struct GenericEvaluator : Evaluator {
         if (!gomoku) { *flops = 0; return ""; }
         const bool fz = fused && blocks > 1;
         *flops = fz ? 2 * conv : conv;
-        if (fz && trunk && trunk_w) return "k_trunk<4,2,RESG> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)";
+        if (fz && trunk && trunk_w) return trunk_m16 ? "k_trunk<RESG, 8 waves> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16)"
+                                                     : "k_trunk<4,2,RESG> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_32x32x16_bf16)";
         return fz ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
                   : "k_conv3x3<128,128> (trunk 3x3 conv, implicit GEMM on MFMA 32x32x16 bf16)";
     }

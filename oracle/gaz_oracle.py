@@ -166,7 +166,7 @@ def selfplay_game_gumbel(game, iteration_limit, max_actions, m, c_visit, c_scale
 
 def selfplay_game(game, run_iterations, max_actions, explore_first, explore_second, c_puct_init, dirichlet_alpha,
                   seed, slot=0, game_seq=0, evaluator=None, hash_salt=0, c_puct_base=19652.0, create_new_root=False,
-                  use_libm=False, gumbel=None, opening_actions=None):
+                  use_libm=False, gumbel=None, opening_actions=None, live=None):
     """Play one PUCT self-play game with the oracle.  evaluator(state_i8[H,W,C]) -> (policy f32[A], value f32),
     or None for the built-in hash evaluator.  Returns a dict of numpy arrays (see gaz_sp_record)."""
     L = lib()
@@ -174,6 +174,8 @@ def selfplay_game(game, run_iterations, max_actions, explore_first, explore_seco
     H, W, Cc, A = GAME_DIMS[gid]
     cap = max_actions + 1
     rec = SPRecord(); rec.cap_T = cap
+    if live is not None:
+        live["rec"] = rec                              # rec.T = plies completed so far, readable from another thread while the game runs
     arrs = dict(states=np.zeros((cap, H, W, Cc), np.int8), policies=np.zeros((cap, A), np.float32),
                 q=np.zeros(cap, np.float32), z=np.zeros(cap, np.float32), values=np.zeros(cap, np.float32),
                 actions=np.zeros(cap, np.int32), root_N=np.zeros((cap, A), np.uint32), root_W=np.zeros((cap, A), np.float32),

@@ -85,6 +85,7 @@ int gaz_selfplay_game(const gaz_sp_config* cfg, gaz_eval_fn eval, void* ctx, uin
         if (n_history == 0) action = gaz_opening_override(cfg, action, seed, slot, game_seq);                       /* :130-140 */
         rec->actions[T] = action;                                                    /* the action PLAYED */
         T++;
+        rec->T = T;                                                                  /* live progress (bench.py's CPU baseline reads it from another thread) */
         gaz_do_action(&g, board, action, next_player); history[n_history++] = action; next_player = -next_player;  /* :142 */
         winner = gaz_check_win(&g, board, -next_player, action);
         if (winner == GAZ_RUNNING) { gaz_puct_prune(mcts[0], action, cfg->create_new_root); gaz_puct_prune(mcts[1], action, cfg->create_new_root); }
