@@ -49,6 +49,8 @@ def parse(argv=None):
     ap.add_argument("--ref-convention-leg", type=int, default=-1, help="1: extra leg at int(1.5 * sims) simulations per move, what Self_Play passes for MCTS_iteration_limit = sims (Self_Play.py:99); default on for the connect4 config at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline-cores", type=int, default=0, help="worker threads = torch threads of the CPU baseline (0 = the cores this "
+                                                                      "process may use: affinity, cut to the cgroup CPU quota)")
     ap.add_argument("--emu-lib", default="", help="TEST HOOK (tests/test_bench_launcher.py): run the bench body on the one-lane CPU emulation build of the "
                                                   "device code over gloo; never a measurement")
     return ap.parse_args(argv)
@@ -114,6 +116,27 @@ def launch(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cores():
+    """CPU cores this process may really use: the scheduler affinity, cut down to the cgroup CPU quota when there is one (a GPU
+    box exposes all of the host's logical CPUs to a container that is only granted a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                    # cgroup v2
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())   # v1
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n
+
+
 def cpu_baseline(args, net):
     """The reference's execution model on this box's host cores: one game per worker, every leaf a blocking
     request to ONE inference server that batches whatever the workers have posted (Client_Server.py:162-217) — here W = all host
@@ -124,7 +147,7 @@ def cpu_baseline(args, net):
     import torch
     from oracle import gaz_oracle as O
     O.build()
-    cores = len(os.sched_getaffinity(0))
+    cores = args.cpu_baseline_cores or host_cores()
     W = cores
     torch.set_num_threads(cores)
     reqs = queue.Queue()

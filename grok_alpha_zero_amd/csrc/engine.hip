@@ -132,15 +132,16 @@ template <class G> GAZ_KERNEL k_probe_rules(DevParams<G> E, const int32_t* actio
     for (int i = 0; i < 3; ++i) h3[i] = (n - 1 - i >= 0) ? (uint8_t)actions[(size_t)p * stride + n - 1 - i] : 0;
     encode_input<G>(S.board, -player, h3, n, o_input + (size_t)p * (G::HW * G::C));
     if (lane_id() == 0) o_winner[p] = winner;
+    if (policy_in && o_policy && n_legal > 0) {
+        DevParams<G> E2 = E; E2.use_dirichlet = 0;
+        make_priors<G>(E2, 0, E.games[0], E.trees[0], 0, S, policy_in + (size_t)p * G::A, n_legal);   // game / tree state: untouched without noise
+        for (int i = lane_id(); i < n_legal; i += WAVE) o_policy[(size_t)p * G::A + S.legal[i]] = S.pri[i];
+        wave_sync();
+    }
     if (winner != RUNNING) return;                                                 // the search never expands a finished position
     bool any_win;
     const int nt = terminal_probe<G>(S.board, S.legal, n_legal, player, S.tact, S.twin, any_win, E.fast_find_win != 0);
     for (int i = lane_id(); i < nt; i += WAVE) o_term[(size_t)p * G::A + S.tact[i]] = S.twin[i] ? 1 : 0;
-    if (policy_in && o_policy) {
-        DevParams<G> E2 = E; E2.use_dirichlet = 0;
-        make_priors<G>(E2, 0, E.games[0], E.trees[0], 0, S, policy_in + (size_t)p * G::A, n_legal);   // game / tree state: untouched without noise
-        for (int i = lane_id(); i < n_legal; i += WAVE) o_policy[(size_t)p * G::A + S.legal[i]] = S.pri[i];
-    }
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {

@@ -82,6 +82,6 @@ def test_cpu_baseline_runs_workers_against_one_batching_server(oracle):
     from grok_alpha_zero_amd.net import Connect4Net
     args = bench.parse(["--sims", "12", "--cpu-baseline-seconds", "3"])
     r = bench.cpu_baseline(args, Connect4Net(1, seed=0).eval())
-    assert r["kind"] == "port" and r["cores"] == len(os.sched_getaffinity(0)) and r["value"] > 0
+    assert r["kind"] == "port" and r["cores"] == bench.host_cores() <= len(os.sched_getaffinity(0)) and r["value"] > 0
     assert r["mean_batch"] > 1.0 or r["cores"] == 1                # requests of several workers really share a forward pass
     assert "whole games" in r["sample"]
