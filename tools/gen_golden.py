@@ -93,6 +93,45 @@ def ref_selfplay_puct(game, iteration_limit, max_actions, explore_first, explore
     return out
 
 
+class NetSession:
+    """session.run backed by a REAL network: the fp32 PyTorch restatement of the reference's ResNet (grok_alpha_zero_amd/net.py,
+    random-init, one thread so the bits do not depend on the machine's core count), batch of one, exactly where the reference's
+    MCTS calls it (MCTS.py:224-235).  Every (input state -> policy, value) pair it answered is kept, so the oracle and the engine
+    can be fed the SAME evaluator outputs through their own session boundary (oracle callback / GAZ_EVAL_EXTERNAL)."""
+
+    def __init__(self, game, blocks, policy_head, net_seed):
+        import torch
+        from grok_alpha_zero_amd.net import NETS
+        torch.set_num_threads(1)
+        self.torch = torch
+        self.net = NETS[game](blocks, seed=net_seed, policy_head=policy_head).eval()
+        self.calls, self.table = 0, {}
+
+    def run(self, output_names, input_feed, **kw):
+        x = np.ascontiguousarray(input_feed["inputs"][0]).astype(np.int8)
+        self.calls += 1
+        key = x.tobytes()
+        if key not in self.table:
+            with self.torch.no_grad():
+                p, v = self.net(self.torch.from_numpy(x[None].copy()))
+            self.table[key] = (p[0].numpy().astype(np.float32).copy(), np.float32(v.reshape(-1)[0].item()))
+        p, v = self.table[key]
+        return [p.reshape(1, -1).copy(), np.array([[v]], np.float32)]
+
+    def arrays(self, shape):
+        keys = list(self.table)
+        return dict(eval_states=np.array([np.frombuffer(k, np.int8).reshape(shape) for k in keys]),
+                    eval_policy=np.array([self.table[k][0] for k in keys]), eval_value=np.array([self.table[k][1] for k in keys], np.float32))
+
+
+NET_CASES = [   # Self_Play.play() with a real random-init ResNet behind session.run (SURVEY 8c: "hash evaluator AND a small random-init ResNet")
+    # name, game, limit, max_actions, ef, es, c_puct, alpha, seed, slot, seq, blocks, net_seed, gumbel
+    ("c4_net_puct_a", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 501, 0, 0, 2, 3, None),
+    ("ttt_net_puct_a", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 502, 1, 0, 2, 4, None),
+    ("c4_net_gumbel_a", "Connect4", 32, 42, 0, 0, 0.0, 0.0, 503, 2, 0, 2, 5, (7, 50.0, 1.0)),
+]
+
+
 PUCT_CASES = [
     # name, game, MCTS_iteration_limit, max_actions, explore_first, explore_second, c_puct_init, alpha, seed, slot, seq, salt
     ("ttt_puct_a", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 1234, 0, 0, 7),       # int(34*1.5) = 51 ~ config[0]'s 50 sims
@@ -215,6 +254,14 @@ def main():
         fx = ref_selfplay_puct(*cfg, opening=opening)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
         print(name, "T =", len(fx["actions"]), "first move", fx["actions"][0], "evals", fx["evaluator_calls"], flush=True)
+    for name, game, it, max_actions, ef, es, cp, alpha, seed, slot, seq, blocks, net_seed, gumbel in NET_CASES:
+        if only and name not in only:
+            continue
+        sess = NetSession(game, blocks, "linear" if gumbel else "softmax", net_seed)
+        fx = ref_selfplay_puct(game, it, max_actions, ef, es, cp, alpha, seed, slot, seq, 0, session=sess, gumbel=gumbel)
+        fx.update(sess.arrays(fx["states"].shape[1:]), net_blocks=blocks, net_seed=net_seed, is_gumbel=int(gumbel is not None))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **fx)
+        print(name, "T =", len(fx["actions"]), "stats", fx["game_stats"], "evals", fx["evaluator_calls"], "distinct states", len(fx["eval_value"]), flush=True)
     for name, *cfg in SINGLE_GUMBEL_CASES:
         if only and name not in only:
             continue
