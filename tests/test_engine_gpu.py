@@ -93,25 +93,137 @@ def test_hip_sync_api_and_host_moves(oracle):
     eng.close()
 
 
-def test_full_size_invariants():
-    """BASELINE config[1] size (4096 concurrent Connect4 games, 200 sims/move) with the synthetic evaluator:
-    size-independent properties — per ply sum(N) over root children == root.visits bookkeeping, policies sum to 1,
-    game_stats consistent, every finished game legal."""
+def _legal_count(game, actions, ply):
+    if game == "Connect4":
+        return int((np.bincount(actions[:ply], minlength=7) < 6).sum())
+    return 225 - ply
+
+
+def _check_puct_invariants(game, r, run_iterations, A, max_actions):
+    """Size-independent properties of one finished PUCT self-play game (MCTS.py:528-618, Self_Play.py:71-157)."""
+    T = r["T"]
+    assert 1 <= T <= max_actions and len(r["actions"]) == T
+    np.testing.assert_allclose(r["policies"].sum(1), 1.0, atol=1e-6)
+    n_sum = r["root_N"].sum(1).astype(np.int64)
+    rv = r["root_visits"].astype(np.int64)
+    # every simulation of run() adds >= 1 visit to the root and to exactly one root edge.  A root made by create_expand_root starts
+    # at 0 visits (sum N == visits); a re-rooted node carries the visit that expanded it (sum N == visits - 1) unless it is a
+    # terminal parent (its creation backed one visit per terminal child up: sum N == visits).
+    assert ((n_sum == rv) | (n_sum == rv - 1)).all(), (n_sum, rv)
+    for ply in range(T):
+        legal = _legal_count(game, r["actions"], ply)
+        lim = 1 if legal == 1 else (run_iterations if run_iterations >= legal else 3 * legal)          # MCTS.py:542-548
+        assert rv[ply] >= lim, (ply, rv[ply], lim)                # the iteration budget was spent (carried visits come on top)
+        assert (r["root_N"][ply] > 0).sum() <= legal and r["root_N"][ply][r["actions"][ply]] > 0     # the played move was searched
+    # both trees are fresh for their first move and nothing can end a game that early: exactly the budget, no carried visits
+    for ply in range(min(2, T)):
+        assert rv[ply] == run_iterations == n_sum[ply], (ply, rv[ply], n_sum[ply])
+    assert np.all(np.abs(r["values"]) <= 1.0) and np.all(np.abs(r["q"]) <= 1.0)
+    z = r["z"]
+    assert r["winner"] in (-1, 0, 1) and (np.all(z == 0) if r["winner"] == 0 else np.all(np.abs(z) == 1))
+
+
+def _first_games(eng, G, want_slots, n_records, max_calls=4000, waves=128):
+    recs = []
+    for _ in range(max_calls):
+        eng.run_waves(waves)
+        recs += eng.drain_finished()
+        have = {r["slot"] for r in recs if r["game_seq"] == 0}
+        if len(recs) >= n_records and want_slots <= have:
+            return recs
+    raise AssertionError(f"only {len(recs)} games finished")
+
+
+def test_full_size_connect4_parity_and_invariants(oracle):
+    """BASELINE configs[1] at its own size — 4096 concurrent Connect4 games, 200 sims/move (synthetic evaluator): the first game of
+    64 slots spread over the batch equals the oracle's game bit for bit, and EVERY finished game satisfies the visit-count
+    bookkeeping of MCTS.run (budget spent, sum N vs root.visits, policies normalised, legal games)."""
     G = 4096
     eng = _engine("Connect4", G, 200, 42, 8, 7, 2.5, 0.5, seed=1, hash_salt=3, ring_capacity=2 * G)
-    recs = _play_until(eng, lambda rs: len(rs) >= 512, max_calls=400, waves=128)
-    for r in recs[:512]:
-        T = r["T"]
-        assert 7 <= T <= 42
-        assert np.allclose(r["policies"].sum(1), 1.0, atol=1e-6)
-        n_sum = r["root_N"].sum(1)
-        assert (n_sum >= 1).all()
-        # a fresh-or-reused root has visits = sum over children (+ carried visits of the reused node itself)
-        assert (r["root_visits"] >= 1).all()
-        cols = np.bincount(r["actions"], minlength=7)
-        assert cols.max() <= 6
+    slots = set(range(0, G, 64))
+    recs = _first_games(eng, G, slots, 1024, max_calls=600)
+    for r in recs:
+        _check_puct_invariants("Connect4", r, 200, 7, 42)
+        assert np.bincount(r["actions"], minlength=7).max() <= 6
+    for r in recs:
+        if r["game_seq"] == 0 and r["slot"] in slots:
+            o = oracle.selfplay_game("Connect4", 200, 42, 8, 7, 2.5, 0.5, 1, r["slot"], 0, hash_salt=3)
+            assert r["T"] == o["T"] and r["winner"] == o["winner"]
+            for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
     st = eng.stats()["game_stats"]
-    assert st[2] >= 512 and st[3] + st[4] + st[5] == st[2] and st[0] <= 42
+    assert st[2] >= 1024 and st[3] + st[4] + st[5] == st[2] and st[0] <= 42
+    eng.close()
+
+
+def test_gomoku_config_parameters_natural_ends_vs_oracle(oracle):
+    """BASELINE configs[3] parameters — Gomoku 15x15, 400 sims/move, c_puct 4.5, alpha 0.05, re-root compaction on (4.2 KB node
+    records) — with max_actions = the whole board so that games end by five in a row INSIDE real games: 64 concurrent games, every
+    first game equal to the oracle's bit for bit (Gomoku had never been compared at depth, nor to a natural end)."""
+    G, iters = 64, 400
+    eng = _engine("Gomoku", G, iters, 225, 6, 4, 4.5, 0.05, seed=77, hash_salt=9, slot_offset=300, ring_capacity=4 * G)
+    recs = _first_games(eng, G, set(range(300, 300 + G)), G, max_calls=20000, waves=256)
+    natural = 0
+    for r in recs:
+        if r["game_seq"] != 0:
+            continue
+        o = oracle.selfplay_game("Gomoku", iters, 225, 6, 4, 4.5, 0.05, 77, r["slot"], 0, hash_salt=9)
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
+        _check_puct_invariants("Gomoku", r, iters, 225, 225)
+        natural += r["winner"] in (-1, 1) and r["T"] < 225
+    assert natural >= G // 2, f"only {natural} of {G} games ended by five in a row"
+    eng.close()
+
+
+def test_full_size_gomoku_parity_and_invariants(oracle):
+    """BASELINE configs[3] at its own size: 2048 concurrent Gomoku games, 400 sims/move, max_actions 150 (bench.py's value), arena
+    with re-root compaction (80 GB of tree records).  First game of 8 slots vs the oracle + invariants on every finished game."""
+    G, iters, max_actions = 2048, 400, 150
+    eng = _engine("Gomoku", G, iters, max_actions, 6, 4, 4.5, 0.05, seed=5, hash_salt=11, ring_capacity=G)
+    slots = set(range(0, G, 256))
+    recs = _first_games(eng, G, slots, 96, max_calls=3000, waves=256)
+    for r in recs:
+        _check_puct_invariants("Gomoku", r, iters, 225, max_actions)
+        assert len(set(r["actions"].tolist())) == r["T"]                  # no cell played twice
+    for r in recs:
+        if r["game_seq"] == 0 and r["slot"] in slots:
+            o = oracle.selfplay_game("Gomoku", iters, max_actions, 6, 4, 4.5, 0.05, 5, r["slot"], 0, hash_salt=11)
+            assert r["T"] == o["T"] and r["winner"] == o["winner"]
+            for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
+    eng.close()
+
+
+def test_full_size_gumbel_parity_and_invariants(oracle):
+    """BASELINE configs[4] at its own size: 8192 concurrent Connect4 games, Gumbel search n = 32, m = 7.  First game of 64 slots vs
+    the oracle; on every finished game: the improved policy is a distribution over legal moves that supports the played move, and the
+    root's visit bookkeeping is consistent (sum N == root.visits: the tree is rebuilt every move, Self_Play.py:151-153)."""
+    from grok_alpha_zero_amd.engine import SEARCH_GUMBEL
+    G, n, m = 8192, 32, 7
+    eng = _engine("Connect4", G, n, 42, 0, 0, 0.0, 0.0, seed=12, hash_salt=4, ring_capacity=2 * G, search=SEARCH_GUMBEL, gumbel_m=m,
+                  c_visit=50.0, c_scale=1.0)
+    slots = set(range(0, G, 128))
+    recs = _first_games(eng, G, slots, 2048, max_calls=600)
+    for r in recs:
+        T = r["T"]
+        assert 7 <= T <= 42 and np.bincount(r["actions"], minlength=7).max() <= 6
+        np.testing.assert_allclose(r["policies"].sum(1), 1.0, atol=1e-5)
+        np.testing.assert_array_equal(r["root_N"].sum(1).astype(np.int64), r["root_visits"].astype(np.int64))   # a fresh tree every move
+        for ply in range(T):
+            full = np.bincount(r["actions"][:ply], minlength=7) >= 6
+            assert (r["policies"][ply][full] == 0).all() and (r["root_N"][ply][full] == 0).all()    # nothing on full columns
+            assert r["policies"][ply][r["actions"][ply]] > 0                                          # the played move has support
+            assert r["root_visits"][ply] <= n * 7 + m           # n simulations (a terminal parent backs up to 7 visits) + m expansions
+    for r in recs:
+        if r["game_seq"] == 0 and r["slot"] in slots:
+            o = oracle.selfplay_game_gumbel("Connect4", n, 42, m, 50.0, 1.0, 12, r["slot"], 0, hash_salt=4)
+            assert r["T"] == o["T"] and r["winner"] == o["winner"]
+            for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+                np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
+            # the opening move's budget: n simulations on top of the m root-child expansions (SURVEY 8d: root.visits = 38)
+            assert o["root_visits"][0] >= n
     eng.close()
 
 
@@ -193,6 +305,24 @@ def test_hip_mcts_class_matches_reference_class(oracle, name):
             break
         mcts.prune_tree(move)
     mcts.close()
+
+
+@pytest.mark.parametrize("name", ["c4_mcts_single_tau", "c4_mcts_single_update"])
+def test_hip_mcts_class_general_tau_and_updates(oracle, name):
+    """tau outside {0, 1} (weights N^(1/tau), MCTS.py:606-610) and update_hyperparams between moves (MCTS.py:134-168) on the GPU,
+    against fixtures recorded from the reference's MCTS class."""
+    from test_mcts_classes import _drive_puct_fixture
+    from grok_alpha_zero_amd.mcts import MCTS
+    _drive_puct_fixture(MCTS, np.load(os.path.join(GOLDEN, name + ".npz")), None, oracle, with_session=False)
+
+
+@pytest.mark.parametrize("name", ["c4_gsingle_nonoise", "c4_gsingle_update"])
+def test_hip_mcts_gumbel_class_without_noise_and_with_updates(oracle, name):
+    """MCTS_Gumbel(use_gumbel_noise=False) (the class default, MCTS_Gumbel.py:157) and update_hyperparams(m, c_visit, c_scale) on the
+    GPU, one session.run per simulation through GAZ_EVAL_EXTERNAL, against fixtures recorded from the reference's class."""
+    from test_mcts_classes import _drive_gumbel_fixture
+    from grok_alpha_zero_amd.mcts import MCTS_Gumbel
+    _drive_gumbel_fixture(MCTS_Gumbel, np.load(os.path.join(GOLDEN, name + ".npz")), None, oracle)
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_open*.npz"))))

@@ -140,6 +140,10 @@ PUCT_CASES = [
     ("c4_puct_b", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 1234, 5, 2, 11),
     ("c4_puct_c", "Connect4", 134, 42, 8, 7, 2.5, 0.5, 99, 17, 0, 3),           # int(134*1.5) = 201 sims (headline n=200)
     ("gmk_puct_a", "Gomoku", 40, 12, 6, 4, 4.5, 0.05, 1234, 0, 0, 5),
+    # Gomoku games that run to a NATURAL end (five in a row inside a real game; max_actions = the whole board).  int(150 * 1.5) = 225
+    # simulations per move = the fewest MCTS.run accepts on an empty 15 x 15 board (iteration_limit < n_legal -> 3 n_legal, MCTS.py:545-546)
+    ("gmk_puct_win_a", "Gomoku", 150, 225, 6, 4, 4.5, 0.05, 78, 1, 0, 9),
+    ("gmk_puct_win_b", "Gomoku", 150, 225, 6, 4, 4.5, 0.05, 4242, 6, 1, 2),
 ]
 
 
@@ -234,6 +238,9 @@ GUMBEL_CASES = [
     ("c4_gumbel_stable_b", "Connect4", 48, 42, 4, 50.0, 0.5, 8, 6, 2, 2, True),
     ("ttt_gumbel_stable_a", "TicTacToe", 16, 9, 4, 50.0, 2.0, 99, 2, 1, 7, True),
     ("gmk_gumbel_stable_a", "Gomoku", 40, 8, 16, 50.0, 1.0, 17, 3, 0, 9, True),
+    # Gomoku Gumbel games to a natural end (max_actions = the whole board)
+    ("gmk_gumbel_win_a", "Gomoku", 16, 225, 4, 50.0, 1.0, 77, 0, 0, 9),
+    ("gmk_gumbel_win_b", "Gomoku", 48, 225, 16, 50.0, 1.0, 91, 5, 0, 3),
 ]
 
 
