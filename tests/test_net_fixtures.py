@@ -14,7 +14,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT
 
-CASES = ["c4_net_puct_a", "ttt_net_puct_a", "c4_net_gumbel_a"]
+CASES = ["c4_netp_a", "ttt_netp_a", "c4_netg_a"]
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 
 

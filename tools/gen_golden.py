@@ -126,9 +126,9 @@ class NetSession:
 
 NET_CASES = [   # Self_Play.play() with a real random-init ResNet behind session.run ("hash evaluator AND a small random-init ResNet")
     # name, game, limit, max_actions, ef, es, c_puct, alpha, seed, slot, seq, blocks, net_seed, gumbel
-    ("c4_net_puct_a", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 501, 0, 0, 2, 3, None),
-    ("ttt_net_puct_a", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 502, 1, 0, 2, 4, None),
-    ("c4_net_gumbel_a", "Connect4", 32, 42, 0, 0, 0.0, 0.0, 503, 2, 0, 2, 5, (7, 50.0, 1.0)),
+    ("c4_netp_a", "Connect4", 40, 42, 8, 7, 2.5, 0.5, 501, 0, 0, 2, 3, None),
+    ("ttt_netp_a", "TicTacToe", 34, 9, 2, 1, 1.25, 1.0, 502, 1, 0, 2, 4, None),
+    ("c4_netg_a", "Connect4", 32, 42, 0, 0, 0.0, 0.0, 503, 2, 0, 2, 5, (7, 50.0, 1.0)),
 ]
 
 
