@@ -216,6 +216,7 @@ struct gaz_engine {
     virtual int stop_search(int) = 0;
     virtual int start_search() = 0;
     virtual int set_hyperparams(const gaz_search_hyperparams*) = 0;
+    virtual int read_head_features(int, float*, float*, int32_t*, int32_t*) = 0;
     virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
 
@@ -566,6 +567,17 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
 
+    int read_head_features(int n, float* p, float* v, int32_t* p_row, int32_t* v_row) override {
+        const float *dp = nullptr, *dv = nullptr; int pr = 0, vr = 0;
+        if (!eval || !eval->head_features(&dp, &dv, &pr, &vr)) return fail("read_head_features: this evaluator keeps no head features");
+        if (n < 0 || n > E.n_games) return fail("read_head_features: n must be in [0, n_games]");
+        if (p_row) *p_row = pr; if (v_row) *v_row = vr;
+        HIP_OK(hipStreamSynchronize(stream));
+        if (p && n) HIP_OK(hipMemcpy(p, dp, (size_t)n * pr * 4, hipMemcpyDeviceToHost));
+        if (v && n) HIP_OK(hipMemcpy(v, dv, (size_t)n * vr * 4, hipMemcpyDeviceToHost));
+        return 0;
+    }
+
     int record_layout(gaz_record_layout* o) override {
         o->record_bytes = RL::SIZE; o->max_T = G::MAXT; o->A = G::A; o->t_pad = G::TPAD;
         o->off_hdr = RL::OFF_HDR; o->off_actions = RL::OFF_ACT; o->off_q = RL::OFF_Q; o->off_root_visits = RL::OFF_RV;
@@ -767,6 +779,7 @@ int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t 
 int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(stop); }
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
+int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p, float* v, int32_t* p_row, int32_t* v_row) { return h->read_head_features(n, p, v, p_row, v_row); }
 int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,
                            uint8_t* legal, int32_t* winner, int8_t* input, int32_t* terminal, const float* policy_in, float* policy_out) {
     return h->probe_rules(actions, n_actions, n_positions, stride, board, legal, winner, input, terminal, policy_in, policy_out);

@@ -24,6 +24,8 @@ struct Evaluator {
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
     // the kernel bench.py prices against the roofline: name and algorithmic FLOPs of one launch at batch n
     virtual const char* dominant_kernel(int n, double* flops) { (void)n; *flops = 0; return ""; }
+    // diagnostics (numerics tests): device pointers of the flat head features the last forward() wrote, f32 [n][row_floats] each
+    virtual bool head_features(const float** p_feat, const float** v_feat, int* p_row_floats, int* v_row_floats) { (void)p_feat; (void)v_feat; (void)p_row_floats; (void)v_row_floats; return false; }
 };
 
 // synthetic evaluator for parity tests: outputs are exact float32 functions of a hash of the input row

@@ -546,6 +546,7 @@ struct ResNetEvaluator : Evaluator {
     }
 
     bool supports_row_base() const override { return true; }
+    bool head_features(const float** p, const float** v, int* pr, int* vr) override { *p = pfeat; *v = vfeat; *pr = HW * 8; *vr = HW * 8; return true; }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         if (!loaded) return;                        // engine_create without weights: outputs stay as they are
         const int M = n * HW;

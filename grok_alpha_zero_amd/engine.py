@@ -93,13 +93,14 @@ def load_library(lib_path=None):
     L.gaz_engine_start_search.argtypes = [H]
     L.gaz_engine_set_hyperparams.argtypes = [H, C.POINTER(SearchHyperparams)]
     L.gaz_engine_probe_rules.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+    L.gaz_engine_read_head_features.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
               "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search",
-              "set_hyperparams", "probe_rules"):
+              "set_hyperparams", "probe_rules", "read_head_features"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -178,6 +179,14 @@ class SelfPlayEngine:
         pol = np.zeros((n, self.A), np.float32); val = np.zeros(n, np.float32); ms = C.c_double()
         self._ck(self.L.gaz_engine_evaluate(self.h, x.ctypes.data, n, pol.ctypes.data, val.ctypes.data, repeats, C.byref(ms)))
         return pol, val, ms.value
+
+    def head_features(self, n):
+        """Flat head features of the last evaluate() call (numerics tests): (p_feat [n, F], v_feat [n, F]) float32."""
+        pr, vr = C.c_int32(), C.c_int32()
+        self._ck(self.L.gaz_engine_read_head_features(self.h, 0, None, None, C.byref(pr), C.byref(vr)))
+        p = np.zeros((n, pr.value), np.float32); v = np.zeros((n, vr.value), np.float32)
+        self._ck(self.L.gaz_engine_read_head_features(self.h, n, p.ctypes.data, v.ctypes.data, None, None))
+        return p, v
 
     # ---- synchronous per-move API ---------------------------------------------------------------------
     def run_move(self):

@@ -143,6 +143,54 @@ class Connect4Net(nn.Module):
         v = torch.tanh(self.v_d3(self.v_d2(F.relu(self.v_bn1(self.v_d1(v))))))
         return p, v
 
+    # ------------------------------------------------------------------ the kernels' arithmetic, restated
+    @torch.no_grad()
+    def forward_engine_numerics(self, x):
+        """The network as csrc/trunk.hpp + csrc/resnet.hip compute it — bf16 operands, fp32 accumulation — with a round-to-nearest-even
+        to bf16 at exactly the points the kernels round (and nowhere else), so the HIP evaluator can be held to a TIGHT tolerance
+        (tests/test_evaluator_gpu.py) instead of the loose bf16-vs-fp32 one:
+          stem     int8 planes x (hi + lo) bf16 split of w * bn_scale, + shift, exact GELU              -> x  = bf16(.)
+          block    a = bf16(relu(x s1 + t1)); h = bf16(relu(conv(a, bf16 w1) s2 + t2')); x = bf16((conv(h, bf16 w2) + b2) + x)
+          heads    f = relu((conv(x, bf16 wh) + bh) fs + ft) in fp32; Dense / softmax / tanh in fp32
+        Convolutions are summed in float64 and rounded to fp32 once (the MFMA's fp32 accumulation order differs from any host
+        order by ~1e-6 relative; the test tolerance covers that and the rare bf16 roundings it flips).  Returns a dict of the head
+        features, logits, pre-tanh value, policy and value."""
+        bf = lambda t: t.float().to(torch.bfloat16).float()
+        B = x.shape[0]
+
+        def conv(a, w):                                  # a [B,H,W,Cin] float32 (bf16-representable), w [3,3,Cin,Cout] -> float32 accumulators
+            y = F.conv2d(a.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=1)
+            return y.permute(0, 2, 3, 1).float()
+        s, t = self.stem_bn.affine()
+        wv = (self.stem.weight * s).float()              # BN scale folded into the fp32 weights (resnet.hip stem_fragments)
+        hi = bf(wv); lo = bf(wv - hi)
+        xs = bf(F.gelu(conv(x.float(), hi.double() + lo.double()) + (self.stem.bias * s + t)))
+        for b in self.blocks:
+            s1, t1 = b.bn1.affine(); s2, t2 = b.bn2.affine()
+            a = bf(F.relu(xs * s1 + t1))
+            h = bf(F.relu(conv(a, bf(b.conv1.weight)) * s2 + (b.conv1.bias * s2 + t2)))
+            xs = bf((conv(h, bf(b.conv2.weight)) + b.conv2.bias) + xs)
+        out = {}
+        z = {}
+        for pre in ("p", "v"):
+            c = getattr(self, pre + "_conv"); s0, t0 = getattr(self, pre + "_bn0").affine()
+            f = F.relu((conv(xs, bf(c.weight)) + c.bias).reshape(B, -1) * s0 + t0)
+            out[pre + "_feat"] = f
+            d1, d2, d3 = getattr(self, pre + "_d1"), getattr(self, pre + "_d2"), getattr(self, pre + "_d3")
+            s1, t1 = getattr(self, pre + "_bn1").affine()
+            y = F.relu((f.double() @ d1.weight.double()).float() * s1 + (d1.bias * s1 + t1))
+            y = (y.double() @ d2.weight.double() + d2.bias.double()).float()
+            z[pre] = (y.double() @ d3.weight.double() + d3.bias.double()).float()
+        out["logits"] = z["p"]; out["v_pre"] = z["v"].reshape(-1)
+        if self.policy_head == "softmax":
+            out["policy"] = torch.softmax(z["p"], -1)    # the kernel's softmax is fp32 (k_tail)
+        elif self.policy_head == "stablemax":
+            out["policy"] = stablemax(z["p"])
+        else:
+            out["policy"] = z["p"]
+        out["value"] = torch.tanh(z["v"]).reshape(-1)
+        return {k: v.numpy() for k, v in out.items()}
+
     # ------------------------------------------------------------------ export for csrc/resnet.hip
     @torch.no_grad()
     def export_engine_weights(self):

@@ -27,6 +27,7 @@
  *   gaz_engine_probe_rules     the Game plugin's static *_MCTS functions          Guide.py:135-283, Game_Tester.py:297-405
  *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
+ *   gaz_engine_read_head_features  intermediate tensors of that probe (numerics tests)  Connect4/Build_Model.py:41-47,62-66
  */
 #ifndef GAZ_ENGINE_H
 #define GAZ_ENGINE_H
@@ -176,6 +177,11 @@ int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t*
 
 /* run the built-in evaluator on a host batch: inputs int8 [n][H*W*C] -> policy f32 [n][A], value f32 [n]; n <= n_games */
 int gaz_engine_evaluate(gaz_engine* h, const int8_t* inputs, int32_t n, float* policy, float* value, int32_t repeats, double* ms_per_batch);
+
+/* diagnostics for the numerics tests: the flat head features the last gaz_engine_evaluate left in HBM — for the Connect4 network
+ * relu(bn0(conv3x3(x) + b)) of the policy and the value head, f32 [n][H*W*8] each (Connect4/Build_Model.py:41-47,62-66), i.e. the
+ * output of stem + every residual block + the heads' first convolution.  *_row_floats receive the row length; p / v may be NULL. */
+int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p_feat, float* v_feat, int32_t* p_row_floats, int32_t* v_row_floats);
 
 int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* out);
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out);

@@ -20,3 +20,11 @@ def oracle():
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def oracle_many(fn, arg_list, threads=8):
+    """Play many oracle games concurrently (the C library holds no per-game global state and ctypes releases the GIL): the oracle
+    is the slow side of the large parity tests."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda a: fn(*a[0], **a[1]), arg_list))

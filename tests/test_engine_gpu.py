@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, oracle_many
 
 pytestmark = pytest.mark.gpu
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*_puct_*.npz")) if "_open" not in p)
@@ -58,10 +58,9 @@ def test_hip_engine_matches_oracle_many_games(oracle, game, G, iters, max_action
                   ring_capacity=4 * G)
     recs = _play_until(eng, lambda rs: len({(r["slot"], r["game_seq"]) for r in rs if r["game_seq"] < 2}) == 2 * G)
     checked = 0
-    for r in recs:
-        if r["game_seq"] >= 2:
-            continue
-        o = oracle.selfplay_game(game, iters, max_actions, ef, es, c, alpha, 2024, r["slot"], r["game_seq"], hash_salt=17)
+    recs = [r for r in recs if r["game_seq"] < 2]
+    ora = oracle_many(oracle.selfplay_game, [((game, iters, max_actions, ef, es, c, alpha, 2024, r["slot"], r["game_seq"]), dict(hash_salt=17)) for r in recs])
+    for r, o in zip(recs, ora):
         assert r["T"] == o["T"] and r["winner"] == o["winner"]
         for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
             np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']} seq {r['game_seq']}")
@@ -115,9 +114,10 @@ def _check_puct_invariants(game, r, run_iterations, A, max_actions):
         lim = 1 if legal == 1 else (run_iterations if run_iterations >= legal else 3 * legal)          # MCTS.py:542-548
         assert rv[ply] >= lim, (ply, rv[ply], lim)                # the iteration budget was spent (carried visits come on top)
         assert (r["root_N"][ply] > 0).sum() <= legal and r["root_N"][ply][r["actions"][ply]] > 0     # the played move was searched
-    # both trees are fresh for their first move and nothing can end a game that early: exactly the budget, no carried visits
+    # both trees are fresh for their first move (tree 2's empty root cannot be re-rooted, MCTS.py:661-671): no carried visits, so
+    # sum N == root.visits exactly; visits exceed the budget only by what terminal parents deep in the tree backed up (MCTS.py:373-380)
     for ply in range(min(2, T)):
-        assert rv[ply] == run_iterations == n_sum[ply], (ply, rv[ply], n_sum[ply])
+        assert n_sum[ply] == rv[ply] and run_iterations <= rv[ply] <= run_iterations + 8 * A, (ply, rv[ply], n_sum[ply])
     assert np.all(np.abs(r["values"]) <= 1.0) and np.all(np.abs(r["q"]) <= 1.0)
     z = r["z"]
     assert r["winner"] in (-1, 0, 1) and (np.all(z == 0) if r["winner"] == 0 else np.all(np.abs(z) == 1))
@@ -164,10 +164,9 @@ def test_gomoku_config_parameters_natural_ends_vs_oracle(oracle):
     eng = _engine("Gomoku", G, iters, 225, 6, 4, 4.5, 0.05, seed=77, hash_salt=9, slot_offset=300, ring_capacity=4 * G)
     recs = _first_games(eng, G, set(range(300, 300 + G)), G, max_calls=20000, waves=256)
     natural = 0
-    for r in recs:
-        if r["game_seq"] != 0:
-            continue
-        o = oracle.selfplay_game("Gomoku", iters, 225, 6, 4, 4.5, 0.05, 77, r["slot"], 0, hash_salt=9)
+    recs = [r for r in recs if r["game_seq"] == 0]
+    ora = oracle_many(oracle.selfplay_game, [(("Gomoku", iters, 225, 6, 4, 4.5, 0.05, 77, r["slot"], 0), dict(hash_salt=9)) for r in recs], threads=12)
+    for r, o in zip(recs, ora):
         assert r["T"] == o["T"] and r["winner"] == o["winner"]
         for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
             np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
@@ -187,9 +186,10 @@ def test_full_size_gomoku_parity_and_invariants(oracle):
     for r in recs:
         _check_puct_invariants("Gomoku", r, iters, 225, max_actions)
         assert len(set(r["actions"].tolist())) == r["T"]                  # no cell played twice
-    for r in recs:
-        if r["game_seq"] == 0 and r["slot"] in slots:
-            o = oracle.selfplay_game("Gomoku", iters, max_actions, 6, 4, 4.5, 0.05, 5, r["slot"], 0, hash_salt=11)
+    cmp = [r for r in recs if r["game_seq"] == 0 and r["slot"] in slots]
+    ora = oracle_many(oracle.selfplay_game, [(("Gomoku", iters, max_actions, 6, 4, 4.5, 0.05, 5, r["slot"], 0), dict(hash_salt=11)) for r in cmp])
+    for r, o in zip(cmp, ora):
+        if True:
             assert r["T"] == o["T"] and r["winner"] == o["winner"]
             for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values"):
                 np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")

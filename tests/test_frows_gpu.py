@@ -1,0 +1,139 @@
+"""GPU suite for the SURVEY 8(f) rows, each against the ORACLE (they had only been tested on the emulation build or
+against themselves):
+  f1 / f4  run_self_play / orchestrator.Run on the HIP engine -> Self_Play_Data.h5 -> read back == the oracle's games + game_stats
+  f3       the on-device evaluation cache ON, compared with oracle.selfplay_game fed by the same HIP network (not cache-off vs cache-on)
+  a14      GAZ_EVAL_EXTERNAL lives in tests/test_net_fixtures.py (reference fixtures through wave_begin / read_batch / write_outputs)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import oracle_many
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+
+
+def _games_in_file(store, n_aug):
+    n = store.n_datasets() // 3 // n_aug
+    return [(store.read(f"boards_{k * n_aug}"), store.read(f"policies_{k * n_aug}"), store.read(f"values_{k * n_aug}")) for k in range(n)]
+
+
+@pytest.mark.parametrize("gumbel", [False, True], ids=["puct", "gumbel"])
+def test_run_self_play_on_hip_writes_the_oracles_games(tmp_path, oracle, gumbel):
+    """f1: a generation played by the HIP engine (evaluation cache on, as run_self_play defaults) and written through h5io.py:
+    the file holds exactly the admitted games {(slot g, k-th game): k * G + g < games}, each equal to the oracle's game — input
+    states, improved policies, values = 0.5 (z + q), the mirrored augmentation — and game_stats equals the oracle's tallies."""
+    _gpu()
+    from grok_alpha_zero_amd.games import GAMES
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    G, games = 64, 150
+    train = dict(games_per_generation=games, MCTS_iteration_limit=32 if gumbel else 40, max_actions=42, num_explore_actions_first=8,
+                 num_explore_actions_second=7, c_puct_init=2.5, dirichlet_alpha=0.5, use_gumbel=gumbel, m=7, c_visit=50.0, c_scale=1.0)
+    assert run_self_play(GAMES["Connect4"], ({}, train), folder, n_games=G, seed=7, hash_salt=3) == games
+    keys = [(g, k) for k in range(3) for g in range(G) if k * G + g < games]
+    if gumbel:
+        ora = oracle_many(oracle.selfplay_game_gumbel, [(("Connect4", 32, 42, 7, 50.0, 1.0, 7, g, k), dict(hash_salt=3)) for g, k in keys])
+    else:
+        ora = oracle_many(oracle.selfplay_game, [(("Connect4", 60, 42, 8, 7, 2.5, 0.5, 7, g, k), dict(hash_salt=3)) for g, k in keys])
+    want = {key: o for key, o in zip(keys, ora)}
+    file_games = _games_in_file(store, 2)
+    assert len(file_games) == games
+    matched = set()
+    for b, p, v in file_games:
+        hit = [key for key, o in want.items() if o["T"] == b.shape[0] and np.array_equal(o["states"], b)]
+        assert len(hit) == 1
+        o = want[hit[0]]
+        np.testing.assert_array_equal(p, o["policies"]); np.testing.assert_array_equal(v.reshape(-1), o["values"])
+        matched.add(hit[0])
+    assert matched == set(want)
+    # the augmentation written next to every game: the left-right mirror (Connect4.py:426-445)
+    b0, p0, _ = file_games[0]
+    np.testing.assert_array_equal(store.read("boards_1"), b0[:, :, ::-1]); np.testing.assert_array_equal(store.read("policies_1"), p0[:, ::-1])
+    gs = store.game_stats()
+    winners = [o["winner"] for o in want.values()]
+    assert gs[2] == games and gs[1] == sum(o["T"] for o in want.values()) and gs[0] == max(o["T"] for o in want.values())
+    assert [gs[3], gs[4], gs[5]] == [winners.count(-1), winners.count(0), winners.count(1)]
+
+
+def test_orchestrator_run_on_hip(tmp_path, oracle):
+    """f4: orchestrator.Run (<Game>/main.py:312-352, self-play half) on the HIP engine: generation folders, resume from game_stats[2],
+    and a generation > 0 played with the HIP ResNet evaluator (weights_fn) — its games equal the oracle's fed by that same network."""
+    _gpu()
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.games import GAMES
+    from grok_alpha_zero_amd.net import Connect4Net
+    from grok_alpha_zero_amd.orchestrator import Run, make_dataset_file, make_generation_folder
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    root = str(tmp_path / "Grok_Zero_Train")
+    train = dict(games_per_generation=24, MCTS_iteration_limit=20, max_actions=42, num_explore_actions_first=8, num_explore_actions_second=7,
+                 c_puct_init=2.5, dirichlet_alpha=0.5, use_gumbel=False, total_generations=2)
+    build = dict(num_resnet_layers=2, num_filters=128)
+    net = Connect4Net(2, seed=9).eval()
+    w = net.export_engine_weights()
+    make_generation_folder(root, 0); make_dataset_file(os.path.join(root, "0"))
+    assert run_self_play(GAMES["Connect4"], (build, dict(train, games_per_generation=10)), os.path.join(root, "0"), n_games=16, seed=5) == 10   # interrupted
+    log = []
+    stats = Run(GAMES["Connect4"], (build, train), train_fn=lambda g, src, dst: None, weights_fn=lambda folder: w, root=root, n_games=16, seed=5,
+                out=log.append)
+    assert [s["generation"] for s in stats] == [0, 1] and stats[0]["played_now"] == 14 and stats[1]["played_now"] == 24
+    for g in range(2):
+        gs = ReplayStore(os.path.join(root, str(g))).game_stats()
+        assert gs[2] == 24 and gs[3] + gs[4] + gs[5] == 24
+    # generation 1 was played with the network: replay four of its games with the oracle, evaluator = the same HIP network
+    probe = SelfPlayEngine("Connect4", 64, 30, 42, 8, 7, 2.5, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=0)
+    probe.load_weights(w)
+
+    def ev(state):
+        p, v, _ = probe.evaluate(state[None])
+        return p[0], v[0]
+    store = ReplayStore(os.path.join(root, "1"))
+    file_games = _games_in_file(store, 2)
+    for slot in (0, 5, 11, 15):
+        o = oracle.selfplay_game("Connect4", 30, 42, 8, 7, 2.5, 0.5, 5 + 1, slot, 0, evaluator=ev)     # Run(seed=S) plays generation g with seed S + g
+        assert any(b.shape[0] == o["T"] and np.array_equal(b, o["states"]) and np.array_equal(p, o["policies"]) for b, p, _ in file_games), slot
+    probe.close()
+
+
+def test_evaluation_cache_on_matches_the_oracle(oracle):
+    """f3: finished games of a run WITH the on-device evaluation cache (ResNet evaluator, a third of the requests answered from HBM)
+    equal oracle.selfplay_game evaluated by the same network one leaf at a time — the cache changes which launches evaluate what,
+    never a result (Session_Cache.py:4-26 is a memo of session.run)."""
+    _gpu()
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=3).eval().export_engine_weights()
+    G, iters = 256, 48
+    eng = SelfPlayEngine("Connect4", G, iters, 42, 8, 7, 2.5, 0.5, seed=21, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=4 * G,
+                         eval_cache_log2=18, games_budget=G)
+    eng.load_weights(w)
+    recs = []
+    for _ in range(400):
+        eng.run_waves(64)
+        recs += eng.drain_finished()
+        if len(recs) == G:
+            break
+    assert len(recs) == G
+    st = eng.stats()
+    assert st["cache_hits"] > 0.15 * st["evals"]
+    eng.close()
+    probe = SelfPlayEngine("Connect4", 64, iters, 42, 8, 7, 2.5, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=0)
+    probe.load_weights(w)
+
+    def ev(state):
+        p, v, _ = probe.evaluate(state[None])
+        return p[0], v[0]
+    by_slot = {r["slot"]: r for r in recs}
+    for slot in range(0, G, 16):
+        o = oracle.selfplay_game("Connect4", iters, 42, 8, 7, 2.5, 0.5, 21, slot, 0, evaluator=ev)
+        r = by_slot[slot]
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q", "evals"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {slot}")
+    probe.close()
