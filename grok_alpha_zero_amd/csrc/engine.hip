@@ -258,7 +258,11 @@ template <class G> struct EngineT : gaz_engine {
         delete eval;
         for (void* p : allocs) hipFree(p);
         for (hipEvent_t e : ev) hipEventDestroy(e);
-        if (pipeline_ready) { hipStreamSynchronize(tstream); for (auto& p : pe) for (hipEvent_t e : p) hipEventDestroy(e); hipStreamDestroy(tstream); }
+        if (pipeline_ready) {
+            hipStreamSynchronize(tstream); hipStreamSynchronize(hstream);
+            for (int p = 0; p < 2; ++p) for (int i = 0; i < n_grp; ++i) { hipEventDestroy(ev_tree_done[p][i]); hipEventDestroy(ev_trunk_done[p][i]); hipEventDestroy(ev_heads_done[p][i]); }
+            hipEventDestroy(ev_join); hipStreamDestroy(tstream); hipStreamDestroy(hstream);
+        }
         hipStreamDestroy(stream);
     }
 
@@ -315,7 +319,7 @@ template <class G> struct EngineT : gaz_engine {
         allocs.push_back(a); E.arena = (uint8_t*)a;
         if (dalloc(&E.trees, (size_t)n * 2)) return 1;
         if (dalloc(&E.games, (size_t)n)) return 1;
-        if (dalloc(&E.paths, (size_t)n * PATH_CAP)) return 1;
+        if (dalloc(&E.paths, (size_t)n * PathCap<G>::V)) return 1;
         if (gumbel) { GumbelState<G>* gp = nullptr; if (dalloc(&gp, (size_t)n)) return 1; E.gstate = gp; }
         if (dalloc(&E.recs, (size_t)n * RL::SIZE)) return 1;
         if (dalloc(&E.ring, (size_t)(cfg.ring_capacity > 0 ? cfg.ring_capacity : 1) * RL::SIZE)) return 1;
@@ -356,7 +360,7 @@ template <class G> struct EngineT : gaz_engine {
         HIP_OK(hipMemcpy(&code, E.error, sizeof(code), hipMemcpyDeviceToHost));
         if (code) {
             const char* names[] = {"", "tree arena full (raise nodes_per_tree)", "root not fully expanded at move end",
-                                   "selection path longer than PATH_CAP", "state-machine loop guard", "PUCT picked an un-poppable child"};
+                                   "selection path longer than the game can last", "state-machine loop guard", "PUCT picked an un-poppable child"};
             return fail(std::string("device error: ") + (code > 0 && code < 6 ? names[code] : "unknown"));
         }
         return 0;
@@ -408,54 +412,74 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
 
-    // ---- two-half pipeline (free-running self-play only).  The games are split in two halves A | B; `stream` carries the
-    // evaluator passes eval(A), eval(B), eval(A), ... back to back, `tstream` the tree steps.  tree(B, k) runs while eval(A, k)
-    // does, tree(A, k + 1) while eval(B, k) does: the tree kernel (one latency-bound wavefront per game, a tenth of the step)
-    // disappears behind the MFMA kernels.  Per-game results do not depend on the split: rows of a batch are independent.
-    hipStream_t tstream = 0;
-    hipEvent_t pe[2][4] = {};                       // [parity][tree A done, tree B done, eval A done, eval B done]
+    // ---- group pipeline (free-running self-play only).  The games are split into K groups; stream `stream` carries nothing but the
+    // trunk kernels trunk(g0, k), trunk(g1, k), ..., trunk(g0, k + 1) back to back — the MFMA kernel is the only thing on the critical
+    // path — while the latency-bound rest runs behind it on two other streams: heads(g, k) (Dense-1 + tail, `hstream`) and the next
+    // tree step tree(g, k + 1) (`tstream`) of a group overlap the trunk launches of the OTHER groups.  Group sizes are whole rounds
+    // of the trunk kernel's tiles (2 workgroups x CUs x 3 boards = 1536 Connect4 boards; the last group may be the cheaper 2-board
+    // tiles), so splitting costs no MFMA round.  Per-game results do not depend on the grouping: rows of a batch are independent.
+    hipStream_t tstream = 0, hstream = 0;
+    static constexpr int MAXGRP = 8;
+    int n_grp = 0, grp0[MAXGRP + 1] = {};
+    hipEvent_t ev_tree_done[2][MAXGRP] = {}, ev_trunk_done[2][MAXGRP] = {}, ev_heads_done[2][MAXGRP] = {}, ev_join = 0;
     bool pipeline_ready = false;
     bool can_pipeline() {
-        // opt-in (GAZ_PIPELINE=1): measured on Connect4 / 4096 games it LOSES 13 % (27.5k vs 31.5k positions/s) — the half-batch
-        // evaluator passes pay the launch gaps and tails of ten small kernels twice, more than the hidden tree step is worth
-        static const bool on = getenv("GAZ_PIPELINE") && atoi(getenv("GAZ_PIPELINE")) != 0;
-        if (!on || E.sync_moves || !eval || !eval->supports_row_base() || E.n_games < 1024 || E.cache) return false;
+        static const char* spec = getenv("GAZ_PIPELINE");
+        if (!spec || !*spec || atoi(spec) == 0) return false;
+        // (the evaluation cache is read by tree kernels and written by k_cache_insert: they must not run concurrently)
+        if (E.sync_moves || !eval || !eval->supports_split() || E.n_games < 1024 || E.cache) return false;
         if (!pipeline_ready) {
-            if (hipStreamCreate(&tstream) != hipSuccess) return false;
-            for (int p = 0; p < 2; ++p) for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&pe[p][i], hipEventDisableTiming);
+            // GAZ_PIPELINE=1: groups of one full trunk round (1536 boards), remainder last; GAZ_PIPELINE=a,b,c: explicit sizes
+            std::vector<int> sizes;
+            if (strchr(spec, ',')) { for (const char* p = spec; *p;) { sizes.push_back(atoi(p)); p = strchr(p, ','); if (!p) break; ++p; } }
+            else { const int round = eval->round_rows(); for (int left = E.n_games; left > 0; left -= round) sizes.push_back(left < round ? left : round); }
+            int sum = 0; for (int v : sizes) sum += v;
+            if (sizes.size() < 2 || sizes.size() > (size_t)MAXGRP || sum != E.n_games) return false;
+            for (int v : sizes) if (v <= 0) return false;
+            n_grp = (int)sizes.size(); grp0[0] = 0;
+            for (int i = 0; i < n_grp; ++i) grp0[i + 1] = grp0[i] + sizes[i];
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);                   // the small kernels should be dispatched ahead of queued trunk tiles
+            if (hipStreamCreateWithPriority(&tstream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+            if (hipStreamCreateWithPriority(&hstream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+            for (int p = 0; p < 2; ++p) for (int i = 0; i < n_grp; ++i) {
+                hipEventCreateWithFlags(&ev_tree_done[p][i], hipEventDisableTiming); hipEventCreateWithFlags(&ev_trunk_done[p][i], hipEventDisableTiming);
+                hipEventCreateWithFlags(&ev_heads_done[p][i], hipEventDisableTiming);
+            }
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
             pipeline_ready = true;
         }
         return true;
     }
     int run_waves_pipelined(int n) {
-        const int gA = E.n_games / 2, gB = E.n_games;
         const int in_row = G::HW * G::C;
-        hipEvent_t e_in = pe[0][0];                 // tstream starts after everything already queued on `stream`
-        hipEventRecord(e_in, stream); hipStreamWaitEvent(tstream, e_in, 0);
+        hipEventRecord(ev_join, stream);                                 // the side streams start after everything queued on `stream`
+        hipStreamWaitEvent(tstream, ev_join, 0); hipStreamWaitEvent(hstream, ev_join, 0);
         for (int k = 0; k < n; ++k) {
-            hipEvent_t* ce = pe[k & 1]; hipEvent_t* le = pe[(k & 1) ^ 1];
-            for (int half = 0; half < 2; ++half) {
-                const int g0 = half ? gA : 0, g1 = half ? gB : gA;
-                if (k > 0) hipStreamWaitEvent(tstream, le[2 + half], 0);            // this half's previous evaluation
+            const int cur = k & 1, prev = cur ^ 1;
+            const bool timed = timing && n_waves_total % TIMING_STRIDE == 0;
+            for (int g = 0; g < n_grp; ++g) {
+                const int g0 = grp0[g], g1 = grp0[g + 1];
+                if (k > 0) hipStreamWaitEvent(tstream, ev_heads_done[prev][g], 0);      // this group's previous evaluation
                 hipEvent_t t0 = 0, t1 = 0;
-                if (timing) { t0 = new_event(); t1 = new_event(); hipEventRecord(t0, tstream); }
+                if (timed) { t0 = new_event(); t1 = new_event(); hipEventRecord(t0, tstream); }
                 launch_wave(tstream, g0, g1);
-                if (timing) { hipEventRecord(t1, tstream); ev_tree.push_back({t0, t1}); }
-                hipEventRecord(ce[half], tstream);
+                if (timed) { hipEventRecord(t1, tstream); ev_tree.push_back({t0, t1}); }
+                hipEventRecord(ev_tree_done[cur][g], tstream);
+                hipStreamWaitEvent(stream, ev_tree_done[cur][g], 0);
+                eval->forward_trunk(stream, E.nn_in + (size_t)g0 * in_row, g1 - g0, timed, g0);
+                hipEventRecord(ev_trunk_done[cur][g], stream);
+                hipStreamWaitEvent(hstream, ev_trunk_done[cur][g], 0);
+                eval->forward_heads(hstream, E.nn_policy + (size_t)g0 * G::A, E.nn_value + g0, g1 - g0, g0);
+                hipEventRecord(ev_heads_done[cur][g], hstream);
             }
-            for (int half = 0; half < 2; ++half) {
-                const int g0 = half ? gA : 0, g1 = half ? gB : gA;
-                hipStreamWaitEvent(stream, ce[half], 0);
-                hipEvent_t v0 = 0, v1 = 0;
-                if (timing) { v0 = new_event(); v1 = new_event(); hipEventRecord(v0, stream); }
-                eval->forward(stream, E.nn_in + (size_t)g0 * in_row, E.nn_policy + (size_t)g0 * G::A, E.nn_value + g0, g1 - g0, timing, g0);
-                if (timing) { hipEventRecord(v1, stream); ev_eval.push_back({v0, v1}); }
-                hipEventRecord(ce[2 + half], stream);
-            }
-            n_waves_total++; if (timing) n_waves_timed++;
+            n_waves_total++; if (timed) n_waves_timed++;
         }
+        // join: `stream` ends after every side-stream kernel, so synchronize() / stats reads on it see a quiescent engine
+        hipEventRecord(ev_join, tstream); hipStreamWaitEvent(stream, ev_join, 0);
+        for (int g = 0; g < n_grp; ++g) hipStreamWaitEvent(stream, ev_heads_done[(n - 1) & 1][g], 0);
         HIP_OK(hipGetLastError());
-        return 0;                                   // `stream` ends with eval(B, n - 1): every tree step is ordered before it
+        return 0;
     }
 
     int counts(int32_t out[10]) {
@@ -612,6 +636,7 @@ template <class G> struct EngineT : gaz_engine {
         for (int i = 0; i < 6; ++i) out[i] = s[i];
         memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
         out[9] = (uint64_t)n_waves_total; memcpy(&out[10], c + 8, 8);
+        out[11] = pipeline_ready ? (uint64_t)n_grp : 0;
         return check_device_error();
     }
 
@@ -707,9 +732,11 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
     int dominant(char* name, int cap, double* flops) override {
-        // positions per evaluator launch: the pipelined run evaluates the two halves of the games separately
-        const int n_launch = can_pipeline() ? E.n_games / 2 : E.n_games;
+        // positions per evaluator launch; the pipelined run launches the trunk kernel once per group: price the MEAN launch (the
+        // timing sums all launches, so FLOPs per launch x launches = FLOPs of the waves either way)
+        const int n_launch = can_pipeline() ? E.n_games / n_grp : E.n_games;
         double f = 0; const char* k = eval ? eval->dominant_kernel(n_launch, &f) : "";
+        if (eval && can_pipeline()) { double fa = 0; eval->dominant_kernel(E.n_games, &fa); f = fa / n_grp; }
         if (name && cap > 0) { strncpy(name, k, cap - 1); name[cap - 1] = 0; }
         if (flops) *flops = f;
         return 0;

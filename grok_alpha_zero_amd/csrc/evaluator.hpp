@@ -19,6 +19,12 @@ struct Evaluator {
     // disjoint row ranges may be in flight on different streams (the engine pipelines two halves of the games)
     virtual void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) = 0;
     virtual bool supports_row_base() const { return false; }
+    // group pipeline (engine.hip run_waves_pipelined): the forward pass in two parts that may run on different streams — the trunk
+    // (input planes of rows [p0, p0 + n) -> head features in the evaluator's own buffers) and the heads (features -> policy / value)
+    virtual bool supports_split() const { return false; }
+    virtual int round_rows() const { return 0; }                  // positions one full round of the trunk kernel's tiles covers
+    virtual void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int p0) { (void)s; (void)in; (void)n; (void)timing; (void)p0; }
+    virtual void forward_heads(hipStream_t s, float* policy, float* value, int n, int p0) { (void)s; (void)policy; (void)value; (void)n; (void)p0; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }

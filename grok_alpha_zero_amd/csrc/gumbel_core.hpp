@@ -400,7 +400,7 @@ template <class G> GAZ_DEV bool g_expand_pre(const DevParams<G>& E, int g, GameS
     }
     uint8_t h3[3] = {(uint8_t)action, ph.hist3[0], ph.hist3[1]};
     encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
-    PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
     for (int d = lane_id(); d <= depth; d += WAVE) gp[d] = S.path[d];
     if (lane_id() == 0) {
         gs.pend_kind = PEND_EXPAND; gs.pend_tree = 0; gs.pend_parent = node; gs.pend_slot = index; gs.pend_node = idx;
@@ -419,7 +419,7 @@ template <class G> GAZ_DEV void g_expand_post(const DevParams<G>& E, int g, Game
     const float value = *value_p;
     if (lane_id() == 0) { pn.child()[index] = idx; node_raw<G>(pn)[index] = value; }       // MCTS_Gumbel.py:516-517
     if (!fresh) {
-        const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+        const PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
         for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
     }
     wave_sync();
@@ -568,7 +568,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             for (;;) {
                 // below the root the record of `node` is already in LDS (staged for its deterministic_selection)
                 const int c = staged ? uni(NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)}.child()[slot]) : uni(node_at(E, g, 0, node).child()[slot]);
-                if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return; }
+                if (depth >= PathCap<G>::V - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return; }
                 if (c == CHILD_NONE) {                                         // expand (node, slot)
                     if (lane_id() == 0) gu.pend_counts = 1;
                     wave_sync();

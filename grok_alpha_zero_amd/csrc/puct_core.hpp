@@ -26,7 +26,8 @@
 
 namespace gaz {
 
-constexpr int PATH_CAP = 256;
+// a selection path is at most as long as the plies left in the game: MAXT edges (+ the leaf edge, + 1 for the overflow test)
+template <class G> struct PathCap { static constexpr int V = (G::MAXT + 3 + 7) / 8 * 8; };
 
 struct PathEnt { int32_t node; int32_t slot; };
 
@@ -54,7 +55,7 @@ template <class G> struct DevParams {
     TreeState* trees;          // [n_games][2]
     GameState<G>* games;       // [n_games]
     void* gstate;              // [n_games] GumbelState (Gumbel search only)
-    PathEnt* paths;            // [n_games][PATH_CAP] path of the pending expansion (root -> leaf edge list)
+    PathEnt* paths;            // [n_games][PathCap<G>::V] path of the pending expansion (root -> leaf edge list)
     uint8_t* recs;             // [n_games][RecLayout::SIZE] game in progress
     uint8_t* ring;             // [ring_cap][RecLayout::SIZE] finished games
     uint32_t* ring_head;       // [2]: produced, consumed
@@ -91,7 +92,7 @@ template <class G> struct Scratch {   // per-wave LDS
     float spri[G::APAD];
     float aux[G::APAD];
     double gam[G::APAD];
-    PathEnt path[PATH_CAP];
+    PathEnt path[PathCap<G>::V];
     uint32_t node[(NodeLayout<G>::OFF_BOARD + 3) / 4];   // header + child arrays of the node being scored (one HBM round trip per level)
     float raw[G::APAD];        // Gumbel: the RAW[] block of that node (evaluator values of the expanded children)
 };
@@ -435,7 +436,7 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
         NodeRef<G> nd{reinterpret_cast<uint8_t*>(S.node)};
         const NodeHdr h = *nd.hdr();
         const int n_actions = uni((int)h.n_actions), n_children = uni((int)h.n_children);
-        if (depth >= PATH_CAP - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return -1; }
+        if (depth >= PathCap<G>::V - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return -1; }
         if (uni((int)h.flags) & NF_TERMINAL_PARENT) {           // MCTS.py:200-208
             // np.sum(child_values) > 0  <=>  some child has W > 0 (all W >= 0 here)
             uint64_t winmask_any = 0; int n_win = 0;
@@ -592,7 +593,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     uint8_t h3[3] = {(uint8_t)action, ph.hist3[0], ph.hist3[1]};
     encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
     // park the path for expand_post
-    PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+    PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
     for (int d = lane_id(); d <= depth; d += WAVE) gp[d] = S.path[d];
     if (lane_id() == 0) {
         gs.pend_kind = PEND_EXPAND; gs.pend_tree = t; gs.pend_parent = node; gs.pend_slot = slot; gs.pend_node = idx;
@@ -619,7 +620,7 @@ template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameSt
     }
     const float value = *value_p;
     if (!fresh) {
-        const PathEnt* gp = E.paths + (size_t)g * PATH_CAP;
+        const PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
         for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
     }
     wave_sync();

@@ -547,14 +547,20 @@ struct ResNetEvaluator : Evaluator {
 
     bool supports_row_base() const override { return true; }
     bool head_features(const float** p, const float** v, int* pr, int* vr) override { *p = pfeat; *v = vfeat; *pr = HW * 8; *vr = HW * 8; return true; }
+    bool supports_split() const override { return fused && trunk && trunk_whole && blocks > 0 && HW <= 128; }
+    int round_rows() const override { return 2 * n_cus * (128 / HW); }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
+        forward_trunk(s, in, n, timing, p0);
+        forward_heads(s, policy, value, n, p0);
+    }
+    // stem + every residual block (+ the heads' first convolution): planes of rows [p0, p0 + n) -> pfeat / vfeat rows [p0, p0 + n)
+    void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int p0) override {
         if (!loaded) return;                        // engine_create without weights: outputs stay as they are
         const int M = n * HW;
         // activation / feature buffers of rows [p0, p0 + n)
         bf16_t* const X = this->X + (size_t)p0 * HW * 128; bf16_t* const X2 = this->X2 + (size_t)p0 * HW * 128;
         bf16_t* const Aa = this->Aa + (size_t)p0 * HW * 128; bf16_t* const Hh = this->Hh + (size_t)p0 * HW * 128;
         float* const pfeat = this->pfeat + (size_t)p0 * HW * 8; float* const vfeat = this->vfeat + (size_t)p0 * HW * 8;
-        float* const pd1 = this->pd1 + (size_t)p0 * 128; float* const vd1 = this->vd1 + (size_t)p0 * 128;
         StemArgs st; st.in = in; st.w = f32["stem.w"]; st.scale = f32["stem.scale"]; st.shift = f32["stem.shift"];
         st.scaleB = blocks ? f32["block0.bn1.scale"] : f32["stem.scale"]; st.shiftB = blocks ? f32["block0.bn1.shift"] : f32["stem.shift"];
         st.out1 = X; st.out2 = fused ? nullptr : Aa; st.M = M; st.H = H; st.W = W;    // the fused blocks pre-activate on load
@@ -644,6 +650,12 @@ struct ResNetEvaluator : Evaluator {
             hc.p_feat = pfeat; hc.v_feat = vfeat; hc.M = M; hc.H = H; hc.W = W;
             hipLaunchKernelGGL(k_conv_heads, dim3((M + HC_ROWS - 1) / HC_ROWS), dim3(RB3_THREADS), hc_lds_bytes(), s, hc);
         }
+    }
+    // Dense-1 (both heads) + tail: pfeat / vfeat rows [p0, p0 + n) -> policy / value
+    void forward_heads(hipStream_t s, float* policy, float* value, int n, int p0) override {
+        if (!loaded) return;
+        float* const pfeat = this->pfeat + (size_t)p0 * HW * 8; float* const vfeat = this->vfeat + (size_t)p0 * HW * 8;
+        float* const pd1 = this->pd1 + (size_t)p0 * 128; float* const vd1 = this->vd1 + (size_t)p0 * 128;
         const int F = HW * 8;
         Dense1Args d; d.B = n; d.F = F;
         d.feat[0] = pfeat; d.w[0] = f32["p.d1.w"]; d.scale[0] = f32["p.d1.scale"]; d.shift[0] = f32["p.d1.shift"]; d.out[0] = pd1;

@@ -33,6 +33,9 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 #define hipEventDisableTiming 0
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = 0; return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+#define hipStreamNonBlocking 0
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = 0; return 0; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define GAZ_LAUNCH(kernel, grid, block, stream, ...)                          \
     do { for (int _b = 0; _b < (int)(grid); ++_b) { gaz::emu_block_id = _b; kernel(__VA_ARGS__); } } while (0)

@@ -295,7 +295,7 @@ class SelfPlayEngine:
         out = (C.c_uint64 * 16)()
         self._ck(self.L.gaz_engine_get_stats(self.h, out))
         s = [int(x) for x in out]
-        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10])
+        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11])
 
     def drain_finished(self, max_records=None):
         """Finished games as dicts: actions, policies [T,A], q, z, values (=0.5(z+q), Self_Play.py:165-172),

@@ -202,35 +202,40 @@ sys.path.insert(0, sys.argv[1])
 from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
 from grok_alpha_zero_amd.net import Connect4Net
 net = Connect4Net(2, seed=3).eval()
-eng = SelfPlayEngine("Connect4", 1024, 24, 12, 4, 3, 2.5, 0.5, seed=11, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=4096)
+eng = SelfPlayEngine("Connect4", 2048, 24, 12, 4, 3, 2.5, 0.5, seed=11, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192)
 eng.load_weights(net.export_engine_weights())
-eng.run_waves(450)
+eng.run_waves(300)
+eng.run_waves(150)
 eng.synchronize()
-recs = eng.drain_finished(4096)
+groups = eng.stats()["pipeline_groups"]
+recs = eng.drain_finished(8192)
 h = hashlib.sha256()
 for r in sorted(recs, key=lambda r: (r["slot"], r["game_seq"])):
     for k in ("slot", "game_seq", "winner", "T"):
         h.update(np.int64(r[k]).tobytes())
     for k in ("actions", "root_N", "root_W", "policies", "q"):
         h.update(np.ascontiguousarray(r[k]).tobytes())
-print(len(recs), h.hexdigest())
+print(groups, len(recs), h.hexdigest())
 """
 
 
-def test_two_half_pipeline_gives_identical_games(tmp_path):
-    """GAZ_PIPELINE=1 (tree step of one half of the games behind the evaluator pass of the other) must not change a single
-    game: same finished records, bit for bit.  The switch is read once per process, hence the subprocesses."""
+def test_group_pipeline_gives_identical_games(tmp_path):
+    """GAZ_PIPELINE (engine.hip run_waves_pipelined: the games in groups, the trunk kernel of one group on the main stream while the
+    heads kernels and the next tree step of the other groups run behind it on two side streams) must not change a single game:
+    same finished records, bit for bit, for the default grouping (one full trunk round + remainder) and an explicit three-group
+    split.  The switch is read once per process, hence the subprocesses."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "pipe.py"; script.write_text(_PIPE_SCRIPT)
-    outs = []
-    for flag in ("0", "1"):
+    outs = {}
+    for flag in ("0", "1", "512,512,1024"):
         env = dict(os.environ, GAZ_PIPELINE=flag)
         r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip().splitlines()[-1])
-    assert int(outs[0].split()[0]) > 200                   # games did finish
-    assert outs[0] == outs[1]
+        outs[flag] = r.stdout.strip().splitlines()[-1].split()
+    assert [outs[f][0] for f in ("0", "1", "512,512,1024")] == ["0", "2", "3"]          # the pipeline really was engaged
+    assert int(outs["0"][1]) > 400                         # games did finish
+    assert outs["0"][1:] == outs["1"][1:] == outs["512,512,1024"][1:]
 
 
 @pytest.mark.parametrize("game,blocks,n", [("Connect4", 3, 200), ("TicTacToe", 2, 64), ("Gomoku", 2, 64)])
@@ -255,28 +260,15 @@ def test_stablemax_policy_head_matches_torch(game, blocks, n):
     eng.close()
 
 
-@pytest.mark.parametrize("blocks,n,mix", [(1, 77, "1"), (1, 77, "0"), (1, 5, "1"), (6, 333, "1"), (6, 333, "0"), (6, 1600, "1")])
-def test_resnet_evaluator_matches_bf16_faithful_reference(blocks, n, mix, monkeypatch):
-    """TIGHT numerics check (the fp32 comparison above, at 6e-2 / 0.15, cannot see a wrong tap at one board edge or a
-    swapped channel group in one layer).  Reference = net.forward_engine_numerics: the same network with a bf16 rounding at exactly
-    the points the kernels round (stem output, pre-activations, h, the residual stream between blocks) and fp32 everywhere else.
-    Compared per element:
-      head features (output of stem + every block + the heads' first conv; with blocks = 1 that is a per-layer check)
-      policy logits and the pre-tanh value      <= 2e-3
-      softmax probabilities, tanh value         <= 1e-3
-    over ragged batches (n not a multiple of the 3 / 2 boards a workgroup owns) and both tile shapes of k_trunk_mix (GAZ_TRUNK_MIX:
-    96-row two-board tiles for the last partial round | 128-row three-board tiles only; 1600 boards = 1024 big + small tiles).
-    What is left between the two sides: the MFMA's accumulation order (~1e-6 relative), the fast-erfc GELU (|err| < 1e-7) and the
-    rare bf16 roundings those flip.  NN numerics vs Keras / ONNX Runtime stay parity unpinned (no TensorFlow, no shipped weights)."""
+def _faithful_metrics(net_factory, blocks, x, mix, monkeypatch):
+    """HIP evaluator vs net.forward_engine_numerics for both policy-head modes -> dict of max / mean differences."""
     import torch
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
-    from grok_alpha_zero_amd.net import Connect4Net
     monkeypatch.setenv("GAZ_TRUNK_MIX", mix)
-    rng = np.random.default_rng(blocks * 1000 + n)
-    x = _random_states(n, rng)
-    ref = None
+    n = x.shape[0]
+    m = {}
     for head, logits_mode in (("linear", 1), ("softmax", 0)):
-        net = Connect4Net(blocks, seed=11, policy_head=head).eval().randomize_bn(7)
+        net = net_factory(head)
         eng = SelfPlayEngine("Connect4", max(n, 64), 200, 42, 8, 7, 2.5, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks,
                              ring_capacity=0, policy_is_logits=logits_mode)
         eng.load_weights(net.export_engine_weights())
@@ -287,20 +279,63 @@ def test_resnet_evaluator_matches_bf16_faithful_reference(blocks, n, mix, monkey
         assert np.isfinite(pol).all() and np.isfinite(val).all()
         for name, got, want in (("p_feat", pf, ref["p_feat"]), ("v_feat", vf, ref["v_feat"])):
             d = np.abs(got - want)
-            scale = np.maximum(np.abs(want), 1.0)
-            assert (d / scale).max() <= 4e-3 and d.mean() <= 2e-4, (name, float((d / scale).max()), float(d.mean()))
-        dv = np.abs(val - ref["value"])
-        assert dv.max() <= 1e-3, ("value", float(dv.max()))
+            m[name + "_rel_max"] = float((d / np.maximum(np.abs(want), 1.0)).max()); m[name + "_mean"] = float(d.mean())
+        m["value_max"] = float(np.abs(val - ref["value"]).max())
         ok = np.abs(ref["v_pre"]) < 2.5                                  # atanh is well conditioned there
-        dz = np.abs(np.arctanh(val[ok].astype(np.float64)) - ref["v_pre"][ok])
-        assert dz.max() <= 2e-3, ("pre-tanh value", float(dz.max()))
+        m["vpre_max"] = float(np.abs(np.arctanh(np.clip(val[ok].astype(np.float64), -0.999999, 0.999999)) - ref["v_pre"][ok]).max()) if ok.any() else 0.0
         if logits_mode:
-            dl = np.abs(pol - ref["logits"])
-            assert dl.max() <= 2e-3, ("logits", float(dl.max()))
+            m["logits_max"] = float(np.abs(pol - ref["logits"]).max())
         else:
-            dp = np.abs(pol - ref["policy"])
-            assert dp.max() <= 1e-3 and np.allclose(pol.sum(1), 1.0, atol=1e-5), ("probabilities", float(dp.max()))
-    # the faithful reference itself stays within bf16 noise of the fp32 network (it is the same network)
-    with torch.no_grad():
-        p32, v32 = net(torch.from_numpy(x))
-    assert np.abs(ref["policy"] - p32.numpy()).max() <= 6e-2 and np.abs(ref["value"] - v32.numpy().reshape(-1)).max() <= 0.15
+            m["prob_max"] = float(np.abs(pol - ref["policy"]).max())
+            assert np.allclose(pol.sum(1), 1.0, atol=1e-5)
+        with torch.no_grad():                                            # the faithful reference is the same network as the fp32 one
+            p32, v32 = net(torch.from_numpy(x))
+        assert np.abs(ref["policy"] - p32.numpy()).max() <= (1.0 if logits_mode else 6e-2) and np.abs(ref["value"] - v32.numpy().reshape(-1)).max() <= 0.15
+    return m
+
+
+@pytest.mark.parametrize("blocks,active,n,mix", [(1, 0, 77, "1"), (1, 0, 77, "0"), (1, 0, 5, "1")] +
+                         [(6, k, 200, "1") for k in range(6)] + [(6, 2, 200, "0"), (6, 5, 1600, "1")])
+def test_resnet_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n, mix, monkeypatch):
+    """TIGHT per-layer numerics check (the fp32 comparison, at 6e-2 / 0.15, cannot see a wrong tap at one board edge or a
+    swapped channel group in one layer).  Reference = net.forward_engine_numerics: the same network with a bf16 rounding at exactly
+    the points the kernels round (stem output, pre-activations, h, the residual stream between blocks), fp32 everywhere else.
+    One residual block is ACTIVE at a time: the convolution weights and conv2 bias of every other block are zero, so those blocks
+    pass the residual stream through bit for bit (x' = bf16((0 + 0) + x) = x) while still running their slice of the fused
+    kernel's weight stream and parameter sets — block k of the 6-block k_trunk_mix launch is then compared at ONE-layer tightness:
+      head features (stem + blocks + heads' first conv), per element      <= 1e-2 of max(|f|, 1) (one bf16 ulp of a flipped rounding), mean <= 1e-4
+      policy logits, pre-tanh value                                        <= 2e-3
+      softmax probabilities, tanh value                                    <= 1e-3
+    over ragged batches and both tile shapes of k_trunk_mix (GAZ_TRUNK_MIX; 1600 boards = 1024 three-board + 32 two-board tiles).
+    What is left between the two sides: the MFMA's accumulation order (~1e-6 relative), the fast-erfc GELU (|err| < 1e-7) and the
+    rare bf16 roundings those flip.  NN numerics vs Keras / ONNX Runtime stay parity unpinned (no TensorFlow, no shipped weights)."""
+    import torch
+    from grok_alpha_zero_amd.net import Connect4Net
+    rng = np.random.default_rng(blocks * 1000 + n + active)
+    x = _random_states(n, rng)
+
+    def factory(head):
+        net = Connect4Net(blocks, seed=11, policy_head=head).eval().randomize_bn(7)
+        with torch.no_grad():
+            for i, b in enumerate(net.blocks):
+                if i != active:
+                    b.conv1.weight.zero_(); b.conv2.weight.zero_(); b.conv2.bias.zero_()
+        return net
+    m = _faithful_metrics(factory, blocks, x, mix, monkeypatch)
+    assert m["p_feat_rel_max"] <= 1e-2 and m["v_feat_rel_max"] <= 1e-2 and m["p_feat_mean"] <= 1e-4 and m["v_feat_mean"] <= 1e-4, m
+    assert m["logits_max"] <= 2e-3 and m["vpre_max"] <= 2e-3 and m["prob_max"] <= 1e-3 and m["value_max"] <= 1e-3, m
+
+
+@pytest.mark.parametrize("blocks,n", [(6, 333), (3, 64)])
+def test_resnet_evaluator_matches_bf16_faithful_reference_end_to_end(blocks, n, monkeypatch):
+    """All blocks active, end to end.  Two bf16 pipelines that differ only in accumulation order do NOT stay within one-layer
+    tightness over 12 stacked convolutions: every flipped rounding perturbs the next layer, which flips more (measured here: mean
+    feature difference grows from 2e-5 after one block to ~1e-2 after six, on features of magnitude ~10).  So the end-to-end bound
+    is the bf16 noise floor of the stack, still several times below the bf16-vs-fp32 bounds of the test above: probabilities 2e-2
+    (there 6e-2), tanh value 5e-2 (there 0.15), mean feature difference 3e-2."""
+    import torch
+    from grok_alpha_zero_amd.net import Connect4Net
+    x = _random_states(n, np.random.default_rng(blocks * 77 + n))
+    m = _faithful_metrics(lambda head: Connect4Net(blocks, seed=11, policy_head=head).eval().randomize_bn(7), blocks, x, "1", monkeypatch)
+    print("end-to-end faithful metrics", blocks, m)
+    assert m["prob_max"] <= 2e-2 and m["value_max"] <= 5e-2 and m["p_feat_mean"] <= 3e-2 and m["v_feat_mean"] <= 3e-2, m
