@@ -21,17 +21,30 @@ template <> struct Game<GAME_TTT> {
     static constexpr int ID = GAME_TTT, H = 3, W = 3, HW = 9, C = 2, A = 9, K = 3;
     static constexpr int APAD = 16, BPAD = 16, MAXT = 9, TPAD = 16;
     static constexpr bool DRAWS = true;
+    static constexpr int TEAM = GAZ_TEAM(64);       // lanes that own one game (wave.hpp "Teams")
 };
 template <> struct Game<GAME_C4> {
     static constexpr int ID = GAME_C4, H = 6, W = 7, HW = 42, C = 4, A = 7, K = 4;
     static constexpr int APAD = 8, BPAD = 48, MAXT = 42, TPAD = 48;
     static constexpr bool DRAWS = true;
+    static constexpr int TEAM = GAZ_TEAM(64);
 };
 template <> struct Game<GAME_GMK> {
     static constexpr int ID = GAME_GMK, H = 15, W = 15, HW = 225, C = 2, A = 225, K = 5;
     static constexpr int APAD = 232, BPAD = 240, MAXT = 225, TPAD = 232;
     static constexpr bool DRAWS = false;   // check_win_MCTS never reports a draw (Gomoku.py:249-255)
+    static constexpr int TEAM = GAZ_TEAM(64);
 };
+
+// The same game stepped by a 16-lane team: FOUR games per wavefront (PUCT tree kernel of the small boards).  Identical rules and
+// record layouts — only the lane mapping differs, so HBM state written by one variant is read by the other.
+#ifndef GAZ_TEAM_LANES
+#define GAZ_TEAM_LANES 16
+#endif
+template <int ID> struct TeamGame : Game<ID> { static constexpr int TEAM = GAZ_TEAM(GAZ_TEAM_LANES); };
+template <class G> struct PuctVariant { typedef G type; };
+template <> struct PuctVariant<Game<GAME_TTT>> { typedef TeamGame<GAME_TTT> type; };
+template <> struct PuctVariant<Game<GAME_C4>> { typedef TeamGame<GAME_C4> type; };
 
 // is action a legal on this board?  (get_legal_actions_MCTS: Connect4.py:271-276 column not full —
 // pieces stack from row 5 upward so "sum |col| < 6" == top cell empty; Gomoku.py:114-119 /

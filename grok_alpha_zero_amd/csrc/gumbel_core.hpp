@@ -662,11 +662,11 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
     GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
     TreeState* tsG = &E.trees[(size_t)g * 2];
     const long long tw0 = GAZ_PROF_NOW();
-    copy_state_words(&L.gs, gsG); copy_state_words(&L.gu, guG); copy_state_words(&L.ts, tsG);
+    copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.gu, guG); copy_state_words<G>(&L.ts, tsG);
     wave_sync();
     g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
     wave_sync();
-    copy_state_words(gsG, &L.gs); copy_state_words(guG, &L.gu); copy_state_words(tsG, &L.ts);
+    copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(guG, &L.gu); copy_state_words<G>(tsG, &L.ts);
     GAZ_PROF(6, tw0);
 }
 

@@ -77,7 +77,7 @@ template <class G> struct DevParams {
 #define GAZ_PROF_NOW() 0ll
 #else
 #define GAZ_PROF_NOW() (E.prof ? (long long)clock64() : 0ll)
-#define GAZ_PROF(k, t0) do { if (E.prof && lane_id() == 0) E.prof[(size_t)g * 8 + (k)] += (unsigned long long)((long long)clock64() - (t0)); } while (0)
+#define GAZ_PROF(k, t0) do { if (E.prof && tlane<G>() == 0) E.prof[(size_t)g * 8 + (k)] += (unsigned long long)((long long)clock64() - (t0)); } while (0)
 #endif
 
 enum : int32_t { ERR_ARENA_FULL = 1, ERR_ROOT_NOT_EXPANDED = 2, ERR_PATH_OVERFLOW = 3, ERR_LOOP_GUARD = 4, ERR_BAD_SELECT = 5 };
@@ -111,8 +111,8 @@ template <class G> GAZ_DEV NodeRef<G> node_at(const DevParams<G>& E, int g, int 
     return NodeRef<G>{E.arena + off};
 }
 
-GAZ_DEV void set_error(int32_t* err, int32_t code) {
-    if (lane_id() == 0 && *err == 0) *err = code;
+GAZ_DEV void set_error(int32_t* err, int32_t code) {      // any lane of any team may report (same value: a benign race)
+    if (*err == 0) *err = code;
 }
 
 template <class G> GAZ_DEV det::Event make_event(const DevParams<G>& E, int g, const GameState<G>& gs, TreeState& ts,
@@ -128,11 +128,11 @@ template <class G> GAZ_DEV det::Event make_event(const DevParams<G>& E, int g, c
 // ballot + prefix popcount compacts (Connect4.py:271-276, Gomoku.py:114-119, Tictactoe.py:186-187).
 template <class G> GAZ_DEV int build_legal(const int8_t* board, uint8_t* out) {
     int n = 0;
-    for (int base = 0; base < G::A; base += WAVE) {
-        int a = base + lane_id();
+    for (int base = 0; base < G::A; base += G::TEAM) {
+        int a = base + tlane<G>();
         bool ok = (a < G::A) && action_legal<G>(board, a);
-        uint64_t m = ballot(ok);
-        if (ok) out[n + popcll(m & ((1ull << lane_id()) - 1ull))] = (uint8_t)a;
+        uint64_t m = tballot<G>(ok);
+        if (ok) out[n + popcll(m & ((1ull << tlane<G>()) - 1ull))] = (uint8_t)a;
         n += popcll(m);
     }
     wave_sync();
@@ -141,9 +141,9 @@ template <class G> GAZ_DEV int build_legal(const int8_t* board, uint8_t* out) {
 
 template <class G> GAZ_DEV int count_empty(const int8_t* board) {
     int n = 0;
-    for (int base = 0; base < G::HW; base += WAVE) {
-        int c = base + lane_id();
-        n += popcll(ballot(c < G::HW && board[c] == 0));
+    for (int base = 0; base < G::HW; base += G::TEAM) {
+        int c = base + tlane<G>();
+        n += popcll(tballot<G>(c < G::HW && board[c] == 0));
     }
     return n;
 }
@@ -151,13 +151,13 @@ template <class G> GAZ_DEV int count_empty(const int8_t* board) {
 // fast_find_win (MCTS.py:282-283, MCTS_Gumbel.py:313): the scan stops at the first winning move in legal-action order.  Draws found
 // before it would be kept too, but a draw needs the last empty cell, i.e. a single legal move, so the result is that one move.
 template <class G> GAZ_DEV bool first_win_only(const int8_t* board, const uint8_t* legal, int n_legal, int player, uint8_t* tact, uint8_t* twin) {
-    for (int base = 0; base < n_legal; base += WAVE) {
-        const int i = base + lane_id();
+    for (int base = 0; base < n_legal; base += G::TEAM) {
+        const int i = base + tlane<G>();
         const bool win = i < n_legal && wins_after<G>(board, landing_cell<G>(board, legal[i]), player);
-        const uint64_t m = ballot(win);
+        const uint64_t m = tballot<G>(win);
         if (m) {
             const int first = base + ffsll0(m);
-            if (lane_id() == 0) { tact[0] = legal[first]; twin[0] = 1; }
+            if (tlane<G>() == 0) { tact[0] = legal[first]; twin[0] = 1; }
             wave_sync();
             return true;
         }
@@ -176,17 +176,17 @@ template <class G> GAZ_DEV int terminal_probe(const int8_t* board, const uint8_t
     // pass 1: wins (descending), pass 2: draws (descending)
     any_win = false;
     for (int pass = 0; pass < ((G::DRAWS && empties == 1) ? 2 : 1); ++pass) {   // a draw needs the last empty cell (wave-uniform)
-        for (int base = ((n_legal - 1) / WAVE) * WAVE; base >= 0; base -= WAVE) {
-            int i = base + lane_id();
+        for (int base = ((n_legal - 1) / G::TEAM) * G::TEAM; base >= 0; base -= G::TEAM) {
+            int i = base + tlane<G>();
             bool hit = false;
             if (i < n_legal) {
                 int a = legal[i];
                 bool win = wins_after<G>(board, landing_cell<G>(board, a), player);
                 hit = (pass == 0) ? win : (!win && empties == 1);
             }
-            uint64_t m = ballot(hit);
+            uint64_t m = tballot<G>(hit);
             if (hit) {
-                int higher = popcll(m >> lane_id()) - 1;   // hits in higher lanes come first
+                int higher = popcll(m >> tlane<G>()) - 1;   // hits in higher lanes come first
                 tact[nt + higher] = legal[i];
                 twin[nt + higher] = (pass == 0) ? 1 : 0;
             }
@@ -216,13 +216,13 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
             }
 #else
             // lanes 0..5 look at one row each; the topmost occupied, not yet removed cell is the lowest set bit (6 = none)
-            const int c = (lane_id() < 6 ? lane_id() : 0) * 7 + x;
-            const uint64_t occ = ballot(lane_id() < 6 && board[c] != 0 && c != rem[0] && c != rem[1] && c != rem[2]);
+            const int c = (tlane<G>() < 6 ? tlane<G>() : 0) * 7 + x;
+            const uint64_t occ = tballot<G>(tlane<G>() < 6 && board[c] != 0 && c != rem[0] && c != rem[1] && c != rem[2]);
             const int y = occ ? ffsll0(occ) : 6;
 #endif
             rem[i] = y * 7 + x;
         }
-        for (int c = lane_id(); c < G::HW; c += WAVE) {
+        for (int c = tlane<G>(); c < G::HW; c += G::TEAM) {
             int8_t b = board[c];
             int8_t p2 = (c == rem[0]) ? 0 : b;
             int8_t p1 = (c == rem[0] || c == rem[1]) ? 0 : b;
@@ -234,7 +234,7 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
             *reinterpret_cast<char4*>(out + c * 4) = v;
         }
     } else {
-        for (int c = lane_id(); c < G::HW; c += WAVE) {
+        for (int c = tlane<G>(); c < G::HW; c += G::TEAM) {
             out[c * 2] = (int8_t)(-current_player);
             out[c * 2 + 1] = board[c];
         }
@@ -257,7 +257,7 @@ template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_action
     else { s = dsqrt(pv); c = puct_c_of(pv, c_init, c_base); }
     const uint32_t* N = nd.N(); const float* Wv = nd.W(); const float* P = nd.P();
     double best = 0.0; int bi = 0x7fffffff;
-    for (int i = lane_id(); i < n_actions; i += WAVE) {
+    for (int i = tlane<G>(); i < n_actions; i += G::TEAM) {
         uint32_t n = N[i]; float w = Wv[i];
         double u = ((double)P[i] * (s / (double)(n + 1u))) * c;
         float q = w;
@@ -265,21 +265,21 @@ template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_action
         double sc = (double)q + u;
         if (bi == 0x7fffffff || sc > best) { best = sc; bi = i; }
     }
-    wave_argmax(best, bi, n_actions);
-    return uni(bi);
+    team_argmax<G>(best, bi);
+    return tuni<G>(bi);
 }
 
 // K8 + K7 + K9: gather legal policy entries, renormalise (numpy pairwise float32 sum), mix Dirichlet noise,
 // sort descending (ties: higher original index first) into S.sact / S.spri.
 template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const GameState<G>& gs, TreeState& ts, int tree,
                                             Scratch<G>& S, const float* policy, int n_legal) {
-    for (int i = lane_id(); i < n_legal; i += WAVE) S.pri[i] = policy[S.legal[i]];
+    for (int i = tlane<G>(); i < n_legal; i += G::TEAM) S.pri[i] = policy[S.legal[i]];
     wave_sync();
     const float sum = det::np_pairwise_sum<float>(S.pri, n_legal);   // uniform: every lane computes the same value
     wave_sync();
     if (E.use_dirichlet) {
         det::Event e = make_event(E, g, gs, ts, tree, det::P_DIRICHLET);
-        for (int i = lane_id(); i < n_legal; i += WAVE) S.gam[i] = det::gamma(e, (uint32_t)i, E.alpha);
+        for (int i = tlane<G>(); i < n_legal; i += G::TEAM) S.gam[i] = det::gamma(e, (uint32_t)i, E.alpha);
         wave_sync();
         double gs_sum = 0.0;                                             // sequential, same in every lane
         if (n_legal <= 8) {                                              // S.gam has >= 8 elements: batch the reads
@@ -291,28 +291,28 @@ template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const 
         } else {
             for (int i = 0; i < n_legal; ++i) gs_sum = gs_sum + S.gam[i];
         }
-        for (int i = lane_id(); i < n_legal; i += WAVE) {
+        for (int i = tlane<G>(); i < n_legal; i += G::TEAM) {
             float p = S.pri[i] / sum;
             float a = E.one_minus_eps * p;
             S.pri[i] = (float)((double)a + E.eps * (S.gam[i] / gs_sum));
         }
-        if (lane_id() == 0) ts.event += 1;
+        if (tlane<G>() == 0) ts.event += 1;
     } else {
-        for (int i = lane_id(); i < n_legal; i += WAVE) S.pri[i] = S.pri[i] / sum;
+        for (int i = tlane<G>(); i < n_legal; i += G::TEAM) S.pri[i] = S.pri[i] / sum;
     }
     wave_sync();
     if (n_legal <= 8) {                                   // rank sort, small node: the eight priors in registers first
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) pv[j] = S.pri[j];
-        for (int i = lane_id(); i < n_legal; i += WAVE) {
+        for (int i = tlane<G>(); i < n_legal; i += G::TEAM) {
             const float v = S.pri[i]; int rank = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) rank += (j < n_legal) && ((pv[j] > v) || (pv[j] == v && j > i));
             S.sact[rank] = S.legal[i]; S.spri[rank] = v;
         }
     } else {
-        for (int i = lane_id(); i < n_legal; i += WAVE) {
+        for (int i = tlane<G>(); i < n_legal; i += G::TEAM) {
             float v = S.pri[i]; int rank = 0;
             for (int j = 0; j < n_legal; ++j) { float o = S.pri[j]; rank += (o > v) || (o == v && j > i); }
             S.sact[rank] = S.legal[i]; S.spri[rank] = v;
@@ -322,33 +322,33 @@ template <class G> GAZ_DEV void make_priors(const DevParams<G>& E, int g, const 
 }
 
 template <class G> GAZ_DEV void write_children_from_scratch(const NodeRef<G>& nd, const Scratch<G>& S, int n) {
-    for (int i = lane_id(); i < n; i += WAVE) {
+    for (int i = tlane<G>(); i < n; i += G::TEAM) {
         nd.N()[i] = 0u; nd.W()[i] = 0.0f; nd.P()[i] = S.spri[i]; nd.child()[i] = CHILD_NONE; nd.act()[i] = S.sact[i];
     }
 }
 
 template <class G> GAZ_DEV void copy_board(int8_t* dst, const int8_t* src) {
-    for (int c = lane_id(); c < G::BPAD; c += WAVE) dst[c] = src[c];
+    for (int c = tlane<G>(); c < G::BPAD; c += G::TEAM) dst[c] = src[c];
 }
 
 // K6: add (value, visits) along the recorded path, sign alternating upward from the leaf edge.
 template <class G> GAZ_DEV void backup(const DevParams<G>& E, int g, int t, TreeState& ts, const PathEnt* path, int depth,
                                        float value, uint32_t visits) {
-    for (int d = lane_id(); d < depth; d += WAVE) {
+    for (int d = tlane<G>(); d < depth; d += G::TEAM) {
         NodeRef<G> nd = node_at(E, g, t, path[d].node);
         float v = ((depth - 1 - d) & 1) ? -value : value;
         int s = path[d].slot;
         nd.W()[s] = nd.W()[s] + v;
         nd.N()[s] = nd.N()[s] + visits;
     }
-    if (lane_id() == 0) ts.root_visits += visits;
+    if (tlane<G>() == 0) ts.root_visits += visits;
     wave_sync();
 }
 
 // terminal parent / terminal root record (K5 and the terminal branch of K12)
 template <class G> GAZ_DEV void write_terminal_children(const NodeRef<G>& nd, const Scratch<G>& S, int nt, bool any_win,
                                                         bool as_root) {
-    for (int i = lane_id(); i < nt; i += WAVE) {
+    for (int i = tlane<G>(); i < nt; i += G::TEAM) {
         float mask = S.twin[i] ? 1.0f : 0.0f;
         nd.N()[i] = 1u;
         // K5: child_values = terminal_mask (MCTS.py:398); K12: every child backed up with value = any_win (MCTS.py:316-344)
@@ -363,7 +363,7 @@ template <class G> GAZ_DEV int alloc_node(const DevParams<G>& E, TreeState& ts) 
     int idx = (int)ts.n_nodes;
     if (idx >= E.nodes_per_tree) { set_error(E.error, ERR_ARENA_FULL); return -1; }
     wave_sync();
-    if (lane_id() == 0) ts.n_nodes = (uint32_t)idx + 1u;
+    if (tlane<G>() == 0) ts.n_nodes = (uint32_t)idx + 1u;
     wave_sync();
     return idx;
 }
@@ -371,7 +371,7 @@ template <class G> GAZ_DEV int alloc_node(const DevParams<G>& E, TreeState& ts) 
 // K12 first half: create_expand_root for tree t at the game's current position.  Returns true when the
 // root needs an evaluation (input row written), false when it was completed here (terminal root).
 template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
-    if (lane_id() == 0) { ts.n_nodes = 0; ts.root = -1; ts.root_visits = 0; }
+    if (tlane<G>() == 0) { ts.n_nodes = 0; ts.root = -1; ts.root_visits = 0; }
     wave_sync();
     copy_board<G>(S.board, gs.board);
     wave_sync();
@@ -383,7 +383,7 @@ template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState
     const int idx = alloc_node(E, ts);
     if (idx < 0) return false;
     NodeRef<G> nd = node_at(E, g, t, idx);
-    if (lane_id() == 0) {
+    if (tlane<G>() == 0) {
         NodeHdr h; memset(&h, 0, sizeof(h));
         h.parent = -1; h.slot = 0; h.player = (int8_t)(-gs.next_player); h.n_hist = (uint16_t)gs.n_hist;
         h.hist3[0] = h3[0]; h.hist3[1] = h3[1]; h.hist3[2] = h3[2]; h.action = h3[0];
@@ -394,7 +394,7 @@ template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState
     copy_board<G>(nd.board(), S.board);
     if (nt > 0) {
         write_terminal_children<G>(nd, S, nt, any_win, true);
-        if (lane_id() == 0) ts.root_visits = (uint64_t)nt;     // one backup per terminal child (MCTS.py:344)
+        if (tlane<G>() == 0) ts.root_visits = (uint64_t)nt;     // one backup per terminal child (MCTS.py:344)
         wave_sync();
         return false;
     }
@@ -413,7 +413,7 @@ template <class G> GAZ_DEV void root_post(const DevParams<G>& E, int g, GameStat
     const int n_legal = build_legal<G>(S.board, S.legal);
     make_priors<G>(E, g, gs, ts, t, S, policy, n_legal);
     write_children_from_scratch<G>(nd, S, n_legal);
-    if (lane_id() == 0) { nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0; }
+    if (tlane<G>() == 0) { nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0; }
     wave_sync();
 }
 
@@ -430,33 +430,33 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
             const uint32_t* src = reinterpret_cast<const uint32_t*>(node_at(E, g, t, node).p);
             constexpr int NW = (NodeLayout<G>::OFF_BOARD + 3) / 4;
             wave_sync();
-            for (int i = lane_id(); i < NW; i += WAVE) S.node[i] = src[i];
+            for (int i = tlane<G>(); i < NW; i += G::TEAM) S.node[i] = src[i];
             wave_sync();
         }
         NodeRef<G> nd{reinterpret_cast<uint8_t*>(S.node)};
         const NodeHdr h = *nd.hdr();
-        const int n_actions = uni((int)h.n_actions), n_children = uni((int)h.n_children);
+        const int n_actions = tuni<G>((int)h.n_actions), n_children = tuni<G>((int)h.n_children);
         if (depth >= PathCap<G>::V - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return -1; }
-        if (uni((int)h.flags) & NF_TERMINAL_PARENT) {           // MCTS.py:200-208
+        if (tuni<G>((int)h.flags) & NF_TERMINAL_PARENT) {           // MCTS.py:200-208
             // np.sum(child_values) > 0  <=>  some child has W > 0 (all W >= 0 here)
             uint64_t winmask_any = 0; int n_win = 0;
-            for (int base = 0; base < n_children; base += WAVE) {
-                int i = base + lane_id();
+            for (int base = 0; base < n_children; base += G::TEAM) {
+                int i = base + tlane<G>();
                 bool pos = (i < n_children) && nd.W()[i] > 0.0f;
-                winmask_any |= ballot(pos);
-                n_win += popcll(ballot((i < n_children) && nd.child()[i] == CHILD_LEAF_WIN));
+                winmask_any |= tballot<G>(pos);
+                n_win += popcll(tballot<G>((i < n_children) && nd.child()[i] == CHILD_LEAF_WIN));
             }
             const bool wins_only = winmask_any != 0;
             const int n_cand = wins_only ? n_win : n_children;
             det::Event e = make_event(E, g, gs, ts, t, det::P_TERMINAL_PICK);
             const int k = (int)det::pick(e, (uint32_t)n_cand);
-            if (lane_id() == 0) ts.event += 1;
+            if (tlane<G>() == 0) ts.event += 1;
             // k-th candidate in child order
             int slot = -1, seen = 0;
-            for (int base = 0; base < n_children && slot < 0; base += WAVE) {
-                int i = base + lane_id();
+            for (int base = 0; base < n_children && slot < 0; base += G::TEAM) {
+                int i = base + tlane<G>();
                 bool c = (i < n_children) && (!wins_only || nd.child()[i] == CHILD_LEAF_WIN);
-                uint64_t m = ballot(c);
+                uint64_t m = tballot<G>(c);
                 int cnt = popcll(m);
                 if (k < seen + cnt) {
                     int want = k - seen;       // want-th set bit of m
@@ -467,7 +467,7 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
                 seen += cnt;
             }
             S.path[depth].node = node; S.path[depth].slot = slot; depth++;
-            leaf_win = uni(nd.child()[slot]) == CHILD_LEAF_WIN;
+            leaf_win = tuni<G>(nd.child()[slot]) == CHILD_LEAF_WIN;
             wave_sync();
             return 1;
         }
@@ -475,8 +475,8 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
         if (best == n_children) { wave_sync(); return 0; }          // MCTS.py:217-218
         if (best > n_children) { set_error(E.error, ERR_BAD_SELECT); return -1; }
         S.path[depth].node = node; S.path[depth].slot = best; depth++;
-        pv = uni(nd.N()[best]);
-        node = uni(nd.child()[best]);
+        pv = tuni<G>(nd.N()[best]);
+        node = tuni<G>(nd.child()[best]);
     }
 }
 
@@ -498,8 +498,9 @@ GAZ_DEV uint64_t mix64(uint64_t x) {
 }
 
 // The row is handled in units of one board cell (C bytes: a dword for Connect4, 16 bits otherwise), one load per unit.
-template <class G> struct CellUnit { typedef uint16_t type; };
-template <> struct CellUnit<Game<GAME_C4>> { typedef uint32_t type; };
+template <int C> struct CellUnitC { typedef uint16_t type; };
+template <> struct CellUnitC<4> { typedef uint32_t type; };
+template <class G> struct CellUnit { typedef typename CellUnitC<G::C>::type type; };
 
 // order-independent 64-bit hash of the encoded row (each lane mixes the cells it owns, the wave adds)
 template <class G> GAZ_DEV uint64_t row_hash(const int8_t* row) {
@@ -507,8 +508,8 @@ template <class G> GAZ_DEV uint64_t row_hash(const int8_t* row) {
     static_assert(sizeof(U) == G::C, "one unit per cell");
     const U* r = reinterpret_cast<const U*>(row);
     uint64_t h = 0;
-    for (int c = lane_id(); c < G::HW; c += WAVE) h += mix64(((uint64_t)(c + 1) << 32) | (uint64_t)r[c]);
-    return wave_sum_u64(h);
+    for (int c = tlane<G>(); c < G::HW; c += G::TEAM) h += mix64(((uint64_t)(c + 1) << 32) | (uint64_t)r[c]);
+    return team_sum_u64<G>(h);
 }
 
 // entry holding the outputs for row g of nn_in, or null.  The caller reads policy / value straight from the entry.
@@ -519,31 +520,32 @@ template <class G> GAZ_DEV const uint8_t* cache_probe(const DevParams<G>& E, int
     const uint64_t h = mix64(row_hash<G>(row));
     const uint8_t* ent = E.cache + (size_t)((uint32_t)h & E.cache_mask) * (size_t)E.cache_stride;
     const uint32_t tag = (uint32_t)(h >> 32) | 1u;
-    if (uni(*reinterpret_cast<const uint32_t*>(ent)) != tag) return nullptr;
+    if (tuni<G>(*reinterpret_cast<const uint32_t*>(ent)) != tag) return nullptr;
     const U* r = reinterpret_cast<const U*>(row); const U* k = reinterpret_cast<const U*>(ent + CL::OFF_KEY);
     bool same = true;
-    for (int c = lane_id(); c < G::HW; c += WAVE) same = same && (k[c] == r[c]);
-    if (ballot(!same) != 0) return nullptr;
+    for (int c = tlane<G>(); c < G::HW; c += G::TEAM) same = same && (k[c] == r[c]);
+    if (tballot<G>(!same) != 0) return nullptr;
     return ent;
 }
 
 // k_cache_insert body: game g's pending request was evaluated this wave -> store (row, outputs)
 template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
     using CL = CacheLayout<G>;
-    if (uni(E.games[g].pend_kind) == PEND_NONE) return;
+    if (tuni<G>(E.games[g].pend_kind) == PEND_NONE) return;
     const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
     const uint64_t h = mix64(row_hash<G>(row));
     const uint32_t slot = (uint32_t)h & E.cache_mask;
     uint32_t prev = 0;
-    if (lane_id() == 0) prev = atomic_exch(&E.cache_lock[slot], E.cache_epoch);     // one writer per slot and wave
-    if (uni(prev) == E.cache_epoch) return;
+    if (tlane<G>() == 0) prev = atomic_exch(&E.cache_lock[slot], E.cache_epoch);     // one writer per slot and wave
+    prev = tshfl<G>(prev, 0);
+    if (prev == E.cache_epoch) return;
     uint8_t* ent = E.cache + (size_t)slot * (size_t)E.cache_stride;
     typedef typename CellUnit<G>::type U;
     const U* r = reinterpret_cast<const U*>(row); U* k = reinterpret_cast<U*>(ent + CL::OFF_KEY);
-    for (int c = lane_id(); c < G::HW; c += WAVE) k[c] = r[c];
+    for (int c = tlane<G>(); c < G::HW; c += G::TEAM) k[c] = r[c];
     float* pol = reinterpret_cast<float*>(ent + CL::OFF_POL);
-    for (int a = lane_id(); a < G::A; a += WAVE) pol[a] = E.nn_policy[(size_t)g * G::A + a];
-    if (lane_id() == 0) {
+    for (int a = tlane<G>(); a < G::A; a += G::TEAM) pol[a] = E.nn_policy[(size_t)g * G::A + a];
+    if (tlane<G>() == 0) {
         *reinterpret_cast<float*>(ent + CL::OFF_VAL) = E.nn_value[g];
         *reinterpret_cast<uint32_t*>(ent) = (uint32_t)(h >> 32) | 1u;
     }
@@ -557,14 +559,14 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     NodeRef<G> pn = node_at(E, g, t, node);
     const NodeRef<G> ps = staged ? NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)} : pn;
     const NodeHdr ph = *ps.hdr();
-    const int slot = uni((int)ph.n_children);
-    const int action = uni((int)ps.act()[slot]);                       // popleft (MCTS.py:437)
-    const int mover = -(int)uni((int)ph.player);
+    const int slot = tuni<G>((int)ph.n_children);
+    const int action = tuni<G>((int)ps.act()[slot]);                       // popleft (MCTS.py:437)
+    const int mover = -(int)tuni<G>((int)ph.player);
     copy_board<G>(S.board, pn.board());
     wave_sync();
     const int cell = landing_cell<G>(S.board, action);
     wave_sync();
-    if (lane_id() == 0) S.board[cell] = (int8_t)mover;                 // do_action_MCTS (MCTS.py:441)
+    if (tlane<G>() == 0) S.board[cell] = (int8_t)mover;                 // do_action_MCTS (MCTS.py:441)
     wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
     bool any_win;
@@ -572,7 +574,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     const int idx = alloc_node(E, ts);
     if (idx < 0) return false;
     NodeRef<G> nd = node_at(E, g, t, idx);
-    if (lane_id() == 0) {
+    if (tlane<G>() == 0) {
         NodeHdr h; memset(&h, 0, sizeof(h));
         h.parent = node; h.slot = (int16_t)slot; h.player = (int8_t)mover; h.n_hist = (uint16_t)(ph.n_hist + 1);
         h.hist3[0] = (uint8_t)action; h.hist3[1] = ph.hist3[0]; h.hist3[2] = ph.hist3[1]; h.action = (uint8_t)action;
@@ -583,7 +585,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     wave_sync();
     if (nt > 0) {                                                      // K5, MCTS.py:367-428
         write_terminal_children<G>(nd, S, nt, any_win, false);
-        if (lane_id() == 0) { pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1); }
+        if (tlane<G>() == 0) { pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1); }
         wave_sync();
         // value = -(len(terminal_mask)) if any win else 0; visits = len(terminal_mask)  (MCTS.py:373-380, 428)
         backup<G>(E, g, t, ts, S.path, depth + 1, any_win ? -(float)nt : 0.0f, (uint32_t)nt);
@@ -594,8 +596,8 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
     // park the path for expand_post
     PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
-    for (int d = lane_id(); d <= depth; d += WAVE) gp[d] = S.path[d];
-    if (lane_id() == 0) {
+    for (int d = tlane<G>(); d <= depth; d += G::TEAM) gp[d] = S.path[d];
+    if (tlane<G>() == 0) {
         gs.pend_kind = PEND_EXPAND; gs.pend_tree = t; gs.pend_parent = node; gs.pend_slot = slot; gs.pend_node = idx;
         gs.pend_depth = depth + 1;
     }
@@ -614,14 +616,14 @@ template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameSt
     make_priors<G>(E, g, gs, ts, t, S, policy, n_legal);
     write_children_from_scratch<G>(nd, S, n_legal);
     NodeRef<G> pn = node_at(E, g, t, node);
-    if (lane_id() == 0) {
+    if (tlane<G>() == 0) {
         nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0;
         pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1);
     }
     const float value = *value_p;
     if (!fresh) {
         const PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
-        for (int d = lane_id(); d < depth; d += WAVE) S.path[d] = gp[d];
+        for (int d = tlane<G>(); d < depth; d += G::TEAM) S.path[d] = gp[d];
     }
     wave_sync();
     backup<G>(E, g, t, ts, S.path, depth, -value, 1u);                 // MCTS.py:511
@@ -638,29 +640,29 @@ template <class G> GAZ_DEV int compact_subtree(const DevParams<G>& E, int g, int
     auto copy_rec = [&](int dst, int src) {
         const uint4* s4 = reinterpret_cast<const uint4*>(base_o + (size_t)src * nb);
         uint4* d4 = reinterpret_cast<uint4*>(base_n + (size_t)dst * nb);
-        for (int i = lane_id(); i < words; i += WAVE) d4[i] = s4[i];
+        for (int i = tlane<G>(); i < words; i += G::TEAM) d4[i] = s4[i];
     };
     copy_rec(0, root_old);
     wave_sync();
-    if (lane_id() == 0) reinterpret_cast<NodeHdr*>(base_n)->parent = -1;
+    if (tlane<G>() == 0) reinterpret_cast<NodeHdr*>(base_n)->parent = -1;
     int n_new = 1;
     for (int i = 0; i < n_new; ++i) {
         NodeRef<G> nd{base_n + (size_t)i * nb};
         wave_sync();
-        if (uni((int)nd.hdr()->flags) & NF_TERMINAL_PARENT) continue;          // children are leaf codes, no records
-        const int nch = uni((int)nd.hdr()->n_children);
+        if (tuni<G>((int)nd.hdr()->flags) & NF_TERMINAL_PARENT) continue;          // children are leaf codes, no records
+        const int nch = tuni<G>((int)nd.hdr()->n_children);
         for (int s = 0; s < nch; ++s) {
-            const int c = uni(nd.child()[s]);
+            const int c = tuni<G>(nd.child()[s]);
             if (c < 0) continue;
             if (n_new >= E.nodes_per_tree) { set_error(E.error, ERR_ARENA_FULL); return -1; }
             copy_rec(n_new, c);
             wave_sync();
-            if (lane_id() == 0) { nd.child()[s] = n_new; reinterpret_cast<NodeHdr*>(base_n + (size_t)n_new * nb)->parent = i; }
+            if (tlane<G>() == 0) { nd.child()[s] = n_new; reinterpret_cast<NodeHdr*>(base_n + (size_t)n_new * nb)->parent = i; }
             n_new++;
         }
     }
     wave_sync();
-    if (lane_id() == 0) { ts.half = (uint32_t)nh; ts.root = 0; ts.n_nodes = (uint32_t)n_new; }
+    if (tlane<G>() == 0) { ts.half = (uint32_t)nh; ts.root = 0; ts.n_nodes = (uint32_t)n_new; }
     wave_sync();
     return n_new;
 }
@@ -670,22 +672,22 @@ template <class G> GAZ_DEV int compact_subtree(const DevParams<G>& E, int g, int
 template <class G> GAZ_DEV bool prune(const DevParams<G>& E, int g, TreeState& ts, int t, int action) {
     if (E.create_new_root || ts.root < 0) return true;
     NodeRef<G> r = node_at(E, g, t, ts.root);
-    const int n_children = uni((int)r.hdr()->n_children);
+    const int n_children = tuni<G>((int)r.hdr()->n_children);
     int found = -1;
-    for (int base = 0; base < n_children; base += WAVE) {
-        int i = base + lane_id();
-        uint64_t m = ballot(i < n_children && r.act()[i] == (uint8_t)action);
+    for (int base = 0; base < n_children; base += G::TEAM) {
+        int i = base + tlane<G>();
+        uint64_t m = tballot<G>(i < n_children && r.act()[i] == (uint8_t)action);
         if (m) { found = base + ffsll0(m); break; }
     }
     if (found < 0) return true;
-    const int c = uni(r.child()[found]);
+    const int c = tuni<G>(r.child()[found]);
     if (c < 0) return true;                                           // (terminal leaf: never pruned on a live game)
-    const uint32_t v = uni(r.N()[found]);
+    const uint32_t v = tuni<G>(r.N()[found]);
     wave_sync();
     if (E.compact) {
         if (compact_subtree<G>(E, g, t, ts, c) < 0) return false;
-        if (lane_id() == 0) ts.root_visits = (uint64_t)v;
-    } else if (lane_id() == 0) { ts.root = c; ts.root_visits = (uint64_t)v; }   // MCTS.py:654-655
+        if (tlane<G>() == 0) ts.root_visits = (uint64_t)v;
+    } else if (tlane<G>() == 0) { ts.root = c; ts.root_visits = (uint64_t)v; }   // MCTS.py:654-655
     wave_sync();
     return false;
 }
@@ -696,19 +698,19 @@ template <class G> GAZ_DEV uint8_t* rec_of(const DevParams<G>& E, int g) { retur
 template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState<G>& gs, TreeState& ts, int t, Scratch<G>& S) {
     using RL = RecLayout<G>;
     NodeRef<G> r = node_at(E, g, t, ts.root);
-    const int n = uni((int)r.hdr()->n_children);
-    if (n != uni((int)r.hdr()->n_actions)) { set_error(E.error, ERR_ROOT_NOT_EXPANDED); }
+    const int n = tuni<G>((int)r.hdr()->n_children);
+    if (n != tuni<G>((int)r.hdr()->n_actions)) { set_error(E.error, ERR_ROOT_NOT_EXPANDED); }
     uint8_t* rec = rec_of(E, g);
     const int ply = gs.n_hist;
     float* pol = reinterpret_cast<float*>(rec + RL::OFF_POL) + (size_t)ply * G::A;
     uint32_t* rN = reinterpret_cast<uint32_t*>(rec + RL::OFF_N) + (size_t)ply * G::A;
     float* rW = reinterpret_cast<float*>(rec + RL::OFF_W) + (size_t)ply * G::A;
     float* rP = reinterpret_cast<float*>(rec + RL::OFF_P) + (size_t)ply * G::A;
-    for (int a = lane_id(); a < G::A; a += WAVE) { pol[a] = 0.0f; rN[a] = 0u; rW[a] = 0.0f; rP[a] = 0.0f; }
+    for (int a = tlane<G>(); a < G::A; a += G::TEAM) { pol[a] = 0.0f; rN[a] = 0u; rW[a] = 0.0f; rP[a] = 0.0f; }
     wave_sync();
     unsigned long long sumv = 0;
     for (int i = 0; i < n; ++i) sumv += r.N()[i];
-    for (int i = lane_id(); i < n; i += WAVE) {
+    for (int i = tlane<G>(); i < n; i += G::TEAM) {
         int a = r.act()[i];
         pol[a] = (float)((double)r.N()[i] / (double)sumv);           // prob = N / sum(N)  (MCTS.py:594, Connect4.py:421-424)
         rN[a] = r.N()[i]; rW[a] = r.W()[i]; rP[a] = r.P()[i];
@@ -719,17 +721,17 @@ template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState
     const double u = det::uniform(e);
     if (!gs.tau_on[t]) {                                               // tau == 0: one-hot at first argmax N (MCTS.py:602-604)
         uint32_t bv = 0; int bi = 0x7fffffff;
-        for (int i = lane_id(); i < n; i += WAVE) { uint32_t v = r.N()[i]; if (bi == 0x7fffffff || v > bv) { bv = v; bi = i; } }
-        wave_argmax_u32(bv, bi);
-        chosen = uni(bi);
+        for (int i = tlane<G>(); i < n; i += G::TEAM) { uint32_t v = r.N()[i]; if (bi == 0x7fffffff || v > bv) { bv = v; bi = i; } }
+        team_argmax_u32<G>(bv, bi);
+        chosen = tuni<G>(bi);
     } else {                                                           // tau > 0 (MCTS.py:606-612), float64: N^(1/tau) / visits^(1/tau)
         const double ex = (E.tau > 0.0) ? 1.0 / E.tau : 1.0;           // Self_Play's schedule only ever sets tau = 1
         if (ex == 1.0) {                                               // x ** 1.0 == x exactly
             const double den = (double)ts.root_visits;
-            for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = (double)r.N()[i] / den;
+            for (int i = tlane<G>(); i < n; i += G::TEAM) S.gam[i] = (double)r.N()[i] / den;
         } else {                                                       // det::dpow stands in for libm pow (< 1e-14 relative: the sampled
             const double den = det::dpow((double)ts.root_visits, ex);  // move differs only if u lands within that of a cdf step)
-            for (int i = lane_id(); i < n; i += WAVE) S.gam[i] = det::dpow((double)r.N()[i], ex) / den;
+            for (int i = tlane<G>(); i < n; i += G::TEAM) S.gam[i] = det::dpow((double)r.N()[i], ex) / den;
         }
         wave_sync();
         const double s = det::np_pairwise_sum<double>(S.gam, n);
@@ -739,7 +741,7 @@ template <class G> GAZ_DEV void move_end(const DevParams<G>& E, int g, GameState
         for (int i = 0; i < n; ++i) { acc = acc + S.gam[i] / s; if (acc / last > u) { chosen = i; break; } }
         wave_sync();
     }
-    if (lane_id() == 0) {
+    if (tlane<G>() == 0) {
         ts.event += 1;
         gs.chosen = r.act()[chosen];
         reinterpret_cast<float*>(rec + RL::OFF_Q)[ply] = (float)((double)r.W()[chosen] / (double)r.N()[chosen]);   // Self_Play.py:117-125
@@ -770,19 +772,19 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
     using RL = RecLayout<G>;
     if (E.ring_cap > 0) {
         int slot = -1;
-        if (lane_id() == 0) {                                          // single consumer (host, between launches) / many producers
+        if (tlane<G>() == 0) {                                          // single consumer (host, between launches) / many producers
             uint32_t prod = atomic_add(&E.ring_head[0], 1u);
             if (prod - E.ring_head[1] < (uint32_t)E.ring_cap) slot = (int)(prod % (uint32_t)E.ring_cap);
             else atomic_add(&E.ring_head[0], (uint32_t)-1);
         }
-        slot = shfl(slot, 0);
+        slot = tshfl<G>(slot, 0);
         if (slot < 0) return false;                                    // ring full: retry next launch
         const uint4* src = reinterpret_cast<const uint4*>(rec_of(E, g));
         uint4* dst = reinterpret_cast<uint4*>(E.ring + (size_t)slot * RL::SIZE);
-        for (int i = lane_id(); i < RL::SIZE / 16; i += WAVE) dst[i] = src[i];
+        for (int i = tlane<G>(); i < RL::SIZE / 16; i += G::TEAM) dst[i] = src[i];
         wave_sync();
     }
-    if (lane_id() == 0) {
+    if (tlane<G>() == 0) {
         if (E.sync_moves) gs.phase = PH_HALT;
         else {
             gs.game_seq += 1;
@@ -800,26 +802,26 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
     using RL = RecLayout<G>;
 
     const long long tp0 = GAZ_PROF_NOW();
-    if (E.prof && lane_id() == 0) E.prof[(size_t)g * 8 + 7] += 1;
-    if (uni(gs.pend_kind) == PEND_ROOT) {
-        const int t = uni(gs.pend_tree);
+    if (E.prof && tlane<G>() == 0) E.prof[(size_t)g * 8 + 7] += 1;
+    if (tuni<G>(gs.pend_kind) == PEND_ROOT) {
+        const int t = tuni<G>(gs.pend_tree);
         root_post<G>(E, g, gs, trees[t], t, S, E.nn_policy + (size_t)g * G::A);
-        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo &= ~(1 << t); gs.n_evals += 1; }
+        if (tlane<G>() == 0) { gs.pend_kind = PEND_NONE; gs.roots_todo &= ~(1 << t); gs.n_evals += 1; }
         wave_sync();
-    } else if (uni(gs.pend_kind) == PEND_EXPAND) {
-        const int t = uni(gs.pend_tree);
+    } else if (tuni<G>(gs.pend_kind) == PEND_EXPAND) {
+        const int t = tuni<G>(gs.pend_tree);
         expand_post<G>(E, g, gs, trees[t], t, S, E.nn_policy + (size_t)g * G::A, E.nn_value + g, false);
-        if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.sims_done += 1; gs.n_evals += 1; gs.n_sims += 1; gs.move_evals += 1; }
+        if (tlane<G>() == 0) { gs.pend_kind = PEND_NONE; gs.sims_done += 1; gs.n_evals += 1; gs.n_sims += 1; gs.move_evals += 1; }
         wave_sync();
     }
 
     GAZ_PROF(0, tp0);
     int tree_only = 0;   // simulations completed in this launch without an evaluation
     for (int guard = 0; guard < 100000; ++guard) {
-        const int phase = uni(gs.phase);
+        const int phase = tuni<G>(gs.phase);
         if (phase == PH_NEW_GAME) {                                    // Game.__init__ + Self_Play.__init__ (Self_Play.py:37-57)
-            for (int c = lane_id(); c < G::BPAD; c += WAVE) gs.board[c] = 0;
-            if (lane_id() == 0) {
+            for (int c = tlane<G>(); c < G::BPAD; c += G::TEAM) gs.board[c] = 0;
+            if (tlane<G>() == 0) {
                 gs.n_hist = 0; gs.next_player = -1; gs.roots_todo = E.single_tree ? 1 : 3; gs.phase = PH_ROOT; gs.winner = RUNNING;
                 gs.host_move = -1; gs.move_evals = 0;
                 trees[0].root = -1; trees[0].event = 0; trees[0].n_nodes = 0; trees[0].root_visits = 0;
@@ -827,29 +829,29 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             wave_sync();
         } else if (phase == PH_ROOT) {
-            const int todo = uni(gs.roots_todo);
-            if (todo == 0) { if (lane_id() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
+            const int todo = tuni<G>(gs.roots_todo);
+            if (todo == 0) { if (tlane<G>() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
             const int t = (todo & 1) ? 0 : 1;
             if (root_pre<G>(E, g, gs, trees[t], t, S)) {
                 const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
                 if (hit) {                                             // evaluation cache hit: the root is complete in this launch
                     root_post<G>(E, g, gs, trees[t], t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL));
-                    if (lane_id() == 0) { gs.roots_todo &= ~(1 << t); gs.n_evals += 1; gs.n_hits += 1; }
+                    if (tlane<G>() == 0) { gs.roots_todo &= ~(1 << t); gs.n_evals += 1; gs.n_hits += 1; }
                     wave_sync();
                     continue;
                 }
-                if (lane_id() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = t; }
+                if (tlane<G>() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = t; }
                 wave_sync();
                 return;
             }
-            if (lane_id() == 0) gs.roots_todo &= ~(1 << t);
+            if (tlane<G>() == 0) gs.roots_todo &= ~(1 << t);
             wave_sync();
-            if (uni(*E.error)) return;
+            if (tuni<G>(*E.error)) return;
         } else if (phase == PH_MOVE_BEGIN) {                           // Self_Play.py:82-106 + MCTS.run head (MCTS.py:542-558)
             copy_board<G>(S.board, gs.board);
             wave_sync();
             const int len_legal = build_legal<G>(S.board, S.legal);
-            if (lane_id() == 0) {
+            if (tlane<G>() == 0) {
                 const int num = gs.n_hist;
                 gs.tau_on[0] = (num % 2 == 0 && num / 2 < E.explore_first) ? 1 : 0;
                 gs.tau_on[1] = ((num + 1) % 2 == 0 && (num + 1) / 2 < E.explore_second) ? 1 : 0;
@@ -862,52 +864,52 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             wave_sync();
         } else if (phase == PH_SIMS) {                                 // MCTS.run loop body (MCTS.py:560-587)
-            if (uni(gs.sims_done) >= uni(gs.iter_limit) || (E.stop_search && uni(gs.sims_done) > 0)) { if (lane_id() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
-            const int t = uni(gs.runner);
+            if (tuni<G>(gs.sims_done) >= tuni<G>(gs.iter_limit) || (E.stop_search && tuni<G>(gs.sims_done) > 0)) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
+            const int t = tuni<G>(gs.runner);
             TreeState& ts = trees[t];
             NodeRef<G> r = node_at(E, g, t, ts.root);
-            if (!uni(gs.fully_visited)) {                              // 0 not in root.child_visits (MCTS.py:564-565)
-                const int na = uni((int)r.hdr()->n_actions);
+            if (!tuni<G>(gs.fully_visited)) {                              // 0 not in root.child_visits (MCTS.py:564-565)
+                const int na = tuni<G>((int)r.hdr()->n_actions);
                 uint64_t zero = 0;
-                for (int base = 0; base < na; base += WAVE) { int i = base + lane_id(); zero |= ballot(i < na && r.N()[i] == 0u); }
-                if (!zero) { if (lane_id() == 0) gs.fully_visited = 1; wave_sync(); }
+                for (int base = 0; base < na; base += G::TEAM) { int i = base + tlane<G>(); zero |= tballot<G>(i < na && r.N()[i] == 0u); }
+                if (!zero) { if (tlane<G>() == 0) gs.fully_visited = 1; wave_sync(); }
             }
-            if (uni(gs.fully_visited) && (uni((int)r.hdr()->flags) & NF_TERMINAL_PARENT)) {
+            if (tuni<G>(gs.fully_visited) && (tuni<G>((int)r.hdr()->flags) & NF_TERMINAL_PARENT)) {
                 // Root with a terminal move available (MCTS.py:200-208 at depth 0): every remaining simulation is
                 // "pick a terminal child, back up 1 (win) or 0 (draw)" and touches only the root's arrays, so up to 64
                 // of them run at once, one RNG event per lane.  f32 adds of 1.0 onto integral W are exact, so
                 // W += count equals the reference's sequence of += 1.
-                const int nch = uni((int)r.hdr()->n_children);
+                const int nch = tuni<G>((int)r.hdr()->n_children);
                 int n_cand = 0, n_win = 0;
-                for (int base = 0; base < nch; base += WAVE) {
-                    int i = base + lane_id();
-                    uint64_t m = ballot(i < nch && r.child()[i] == CHILD_LEAF_WIN);
-                    if (i < nch && r.child()[i] == CHILD_LEAF_WIN) S.sact[n_win + popcll(m & ((1ull << lane_id()) - 1ull))] = (uint8_t)i;
+                for (int base = 0; base < nch; base += G::TEAM) {
+                    int i = base + tlane<G>();
+                    uint64_t m = tballot<G>(i < nch && r.child()[i] == CHILD_LEAF_WIN);
+                    if (i < nch && r.child()[i] == CHILD_LEAF_WIN) S.sact[n_win + popcll(m & ((1ull << tlane<G>()) - 1ull))] = (uint8_t)i;
                     n_win += popcll(m);
                 }
                 uint64_t anypos = 0;
-                for (int base = 0; base < nch; base += WAVE) { int i = base + lane_id(); anypos |= ballot(i < nch && r.W()[i] > 0.0f); }
+                for (int base = 0; base < nch; base += G::TEAM) { int i = base + tlane<G>(); anypos |= tballot<G>(i < nch && r.W()[i] > 0.0f); }
                 const bool wins_only = anypos != 0;
                 if (wins_only) n_cand = n_win;
-                else { for (int i = lane_id(); i < nch; i += WAVE) S.sact[i] = (uint8_t)i; n_cand = nch; }
+                else { for (int i = tlane<G>(); i < nch; i += G::TEAM) S.sact[i] = (uint8_t)i; n_cand = nch; }
                 wave_sync();
-                const int remaining = uni(gs.iter_limit) - uni(gs.sims_done);
-                const int chunk = remaining < WAVE ? remaining : WAVE;
+                const int remaining = tuni<G>(gs.iter_limit) - tuni<G>(gs.sims_done);
+                const int chunk = remaining < G::TEAM ? remaining : G::TEAM;
                 int my_slot = -1;
-                if (lane_id() < chunk) {
+                if (tlane<G>() < chunk) {
                     det::Event e = make_event(E, g, gs, ts, t, det::P_TERMINAL_PICK);
-                    e.event += (uint32_t)lane_id();
+                    e.event += (uint32_t)tlane<G>();
                     my_slot = S.sact[det::pick(e, (uint32_t)n_cand)];
                 }
                 for (int c = 0; c < n_cand; ++c) {
                     const int slot = S.sact[c];
-                    const int cnt = popcll(ballot(my_slot == slot));
-                    if (lane_id() == 0 && cnt) {
+                    const int cnt = popcll(tballot<G>(my_slot == slot));
+                    if (tlane<G>() == 0 && cnt) {
                         if (r.child()[slot] == CHILD_LEAF_WIN) r.W()[slot] = r.W()[slot] + (float)cnt;
                         r.N()[slot] = r.N()[slot] + (uint32_t)cnt;
                     }
                 }
-                if (lane_id() == 0) {
+                if (tlane<G>() == 0) {
                     ts.root_visits += (uint64_t)chunk; ts.event += (uint32_t)chunk;
                     gs.sims_done += chunk; gs.n_sims += (uint64_t)chunk;
                 }
@@ -918,19 +920,19 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             tree_only++;
             int node, depth; bool leaf_win = false; int kind;
             const long long ts0 = GAZ_PROF_NOW();
-            if (!uni(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
+            if (!tuni<G>(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
             else kind = puct_select<G>(E, g, gs, ts, t, S, node, depth, leaf_win);
             GAZ_PROF(1, ts0);
             if (kind < 0) return;
             if (kind == 1) {                                           // terminal leaf: value 1 / 0, visits 1 (MCTS.py:573-575)
                 const long long tb0 = GAZ_PROF_NOW();
                 backup<G>(E, g, t, ts, S.path, depth, leaf_win ? 1.0f : 0.0f, 1u);
-                if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
+                if (tlane<G>() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
                 GAZ_PROF(5, tb0);
             } else {
                 const long long te0 = GAZ_PROF_NOW();
-                const bool pending = expand_pre<G>(E, g, gs, ts, t, S, node, depth, kind == 0 && uni(gs.fully_visited) != 0);
+                const bool pending = expand_pre<G>(E, g, gs, ts, t, S, node, depth, kind == 0 && tuni<G>(gs.fully_visited) != 0);
                 GAZ_PROF(2, te0);
                 if (pending) {
                     const long long tc0 = GAZ_PROF_NOW();
@@ -940,24 +942,24 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                     const long long tx0 = GAZ_PROF_NOW();
                     expand_post<G>(E, g, gs, ts, t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                    reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: consume the cached outputs now
-                    if (lane_id() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
+                    if (tlane<G>() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                     wave_sync();
                     GAZ_PROF(4, tx0);
                 }
-                if (uni(*E.error)) return;
-                if (lane_id() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
+                if (tuni<G>(*E.error)) return;
+                if (tlane<G>() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
             }
         } else if (phase == PH_MOVE_END) {
-            const int t = uni(gs.runner);
+            const int t = tuni<G>(gs.runner);
             move_end<G>(E, g, gs, trees[t], t, S);
-            if (lane_id() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
+            if (tlane<G>() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
             wave_sync();
             if (E.sync_moves) return;
         } else if (phase == PH_APPLY) {                                // Self_Play.py:142-157
-            int action = (uni(gs.host_move) >= 0) ? uni(gs.host_move) : uni(gs.chosen);
-            if (uni(gs.n_hist) == 0 && uni(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
-            const int mover = uni(gs.next_player);
+            int action = (tuni<G>(gs.host_move) >= 0) ? tuni<G>(gs.host_move) : tuni<G>(gs.chosen);
+            if (tuni<G>(gs.n_hist) == 0 && tuni<G>(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
+            const int mover = tuni<G>(gs.next_player);
             copy_board<G>(S.board, gs.board);
             wave_sync();
             const int cell = landing_cell<G>(S.board, action);
@@ -967,7 +969,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             const int ply = gs.n_hist;
             int winner = win ? mover : ((G::DRAWS && empties == 1) ? 0 : RUNNING);
             wave_sync();
-            if (lane_id() == 0) {
+            if (tlane<G>() == 0) {
                 gs.board[cell] = (int8_t)mover;
                 gs.hist[ply] = (uint8_t)action;
                 rec[RL::OFF_ACT + ply] = (uint8_t)action;
@@ -982,9 +984,9 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             // Self_Play.py:155-157: reaching max_actions forces winner = 0 — even when that last action won
             if (ply + 1 == E.max_actions) { winner = 0; ended = true; }
-            if (!ended && lane_id() == 0) { gs.roots_todo = todo; gs.phase = (E.sync_moves && E.single_tree) ? PH_IDLE : PH_ROOT; }
+            if (!ended && tlane<G>() == 0) { gs.roots_todo = todo; gs.phase = (E.sync_moves && E.single_tree) ? PH_IDLE : PH_ROOT; }
             if (ended) {
-                if (lane_id() == 0) {
+                if (tlane<G>() == 0) {
                     gs.winner = winner;
                     int32_t* hdr = reinterpret_cast<int32_t*>(rec);
                     hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)(E.slot_offset + (uint32_t)g); hdr[3] = (int32_t)gs.game_seq;
@@ -1011,10 +1013,10 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
 // launch works on an LDS copy: one coalesced load on entry, one store on exit.
 template <class G> struct PuctLocal { GameState<G> gs; TreeState ts[2]; };
 
-template <class T> GAZ_DEV void copy_state_words(T* dst, const T* src) {
+template <class G, class T> GAZ_DEV void copy_state_words(T* dst, const T* src) {
     static_assert(sizeof(T) % 4 == 0, "word copy");
     uint32_t* d = reinterpret_cast<uint32_t*>(dst); const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    for (int i = lane_id(); i < (int)(sizeof(T) / 4); i += WAVE) d[i] = s[i];
+    for (int i = tlane<G>(); i < (int)(sizeof(T) / 4); i += G::TEAM) d[i] = s[i];
 }
 
 template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {
@@ -1022,11 +1024,11 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
     TreeState* tsG = E.trees + (size_t)g * 2;
     if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); return; }
     const long long tw0 = GAZ_PROF_NOW();
-    copy_state_words(&L.gs, gsG); copy_state_words(&L.ts[0], &tsG[0]); copy_state_words(&L.ts[1], &tsG[1]);
+    copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.ts[0], &tsG[0]); copy_state_words<G>(&L.ts[1], &tsG[1]);
     wave_sync();
     game_step_body<G>(E, g, S, L.gs, L.ts);
     wave_sync();
-    copy_state_words(gsG, &L.gs); copy_state_words(&tsG[0], &L.ts[0]); copy_state_words(&tsG[1], &L.ts[1]);
+    copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(&tsG[0], &L.ts[0]); copy_state_words<G>(&tsG[1], &L.ts[1]);
     GAZ_PROF(6, tw0);
 }
 

@@ -18,6 +18,7 @@
 #define GAZ_DEV inline
 #define GAZ_HD inline
 #define GAZ_KERNEL inline void
+#define GAZ_KERNEL_TEAMS inline void
 #define GAZ_KERNEL_WIDE inline void
 #define GAZ_SHARED static thread_local
 struct char4 { signed char x, y, z, w; };
@@ -49,6 +50,8 @@ template <class T> inline T atomic_exch(T* p, T v) { T o = *p; *p = v; return o;
 #define GAZ_TREE_WPE 3                             // measured: 0.074 / 0.080 / 0.083 ms per PUCT wave at 3 / 2 / 4
 #endif
 #define GAZ_KERNEL __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAZ_TREE_WPE, GAZ_TREE_WPE))) void
+// four games per wavefront (16-lane teams): one wave per SIMD covers 4096 games, so the register budget is generous
+#define GAZ_KERNEL_TEAMS __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #define GAZ_KERNEL_WIDE __global__ void               // kernels launched with more than one wavefront per workgroup
 #define GAZ_SHARED __shared__
 namespace gaz {
@@ -74,6 +77,68 @@ template <class T> GAZ_DEV T atomic_exch(T* p, T v) { return atomicExch(p, v); }
 #endif
 
 namespace gaz {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Teams: a game is owned by a TEAM of G::TEAM consecutive lanes — the whole wavefront (64) for Gomoku's 225-wide nodes, a 16-lane
+// DPP row for Connect4 / TicTacToe (<= 9 children, <= 42 cells), so that one wavefront steps FOUR games.  The tree kernel is bound
+// by vector-instruction issue (a wave64 instruction costs four cycles whatever the number of live lanes, and a Connect4 node keeps
+// at most 7 of 64 busy): four games per instruction stream cut the instructions issued per game.  Control flow is uniform within a
+// team and may diverge between the teams of a wave (the hardware masks lanes); all cross-lane traffic of a game stays inside its row:
+// ballots are masked to the row, butterflies use xor < TEAM, "uniform" values are per-team VGPRs (read from one address by all lanes
+// of the team, or brought to every lane by a full butterfly), never wave scalars.
+#ifdef GAZ_HOST_EMU
+#define GAZ_TEAM(n) 1
+#else
+#define GAZ_TEAM(n) (n)
+#endif
+template <class G> GAZ_DEV int tlane() { return lane_id() & (G::TEAM - 1); }            // lane within the team
+template <class G> GAZ_DEV int team_in_wave() { return lane_id() / G::TEAM; }            // which of the wave's teams
+template <class G> GAZ_DEV uint64_t tballot(bool p) {                                    // ballot over the team's lanes, bit i = team lane i
+    const uint64_t m = ballot(p);
+    if (G::TEAM >= 64) return m;
+    return (m >> (team_in_wave<G>() * G::TEAM)) & ((1ull << (G::TEAM & 63)) - 1ull);
+}
+template <class G, class T> GAZ_DEV T tshfl(T v, int src) { return shfl(v, team_in_wave<G>() * G::TEAM + src); }   // value of team lane `src`
+// a value every lane of the team already holds (read from one address) — kept in an SGPR when the team is the whole wave
+template <class G, class T> GAZ_DEV T tuni(T v) {
+#ifdef GAZ_HOST_EMU
+    return v;
+#else
+    if (G::TEAM >= 64) return (T)__builtin_amdgcn_readfirstlane((int)v);
+    return v;
+#endif
+}
+// team argmax over (score, index): largest score wins, ties -> LOWEST index; lanes holding no candidate pass idx = INT32_MAX.
+// Full butterfly: EVERY lane of the team ends up with the result.
+template <class G> GAZ_DEV void team_argmax(double& score, int& idx) {
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = G::TEAM / 2; m >= 1; m >>= 1) {
+        double os = shfl_xor(score, m);
+        int oi = shfl_xor(idx, m);
+        bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || os > score || (os == score && oi < idx));
+        if (take) { score = os; idx = oi; }
+    }
+#endif
+}
+template <class G> GAZ_DEV void team_argmax_u32(uint32_t& v, int& idx) {
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = G::TEAM / 2; m >= 1; m >>= 1) {
+        uint32_t ov = shfl_xor(v, m);
+        int oi = shfl_xor(idx, m);
+        bool take = (oi != 0x7fffffff) && (idx == 0x7fffffff || ov > v || (ov == v && oi < idx));
+        if (take) { v = ov; idx = oi; }
+    }
+#endif
+}
+template <class G> GAZ_DEV uint64_t team_sum_u64(uint64_t v) {                            // wrap-around add: order-independent
+#ifndef GAZ_HOST_EMU
+#pragma unroll
+    for (int m = G::TEAM / 2; m >= 1; m >>= 1) v += shfl_xor(v, m);
+#endif
+    return v;
+}
+
 // wave argmax over (score, index): largest score wins, ties -> LOWEST index (np.argmax semantics,
 // MCTS.py:191).  Lanes holding no candidate pass idx = INT32_MAX.
 // `span`: candidates live in lanes [0, span) only (wave-uniform; span = 64 reduces the whole wave).  Lane 0 ends up with the
