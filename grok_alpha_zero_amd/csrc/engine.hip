@@ -237,6 +237,7 @@ template <class G> struct EngineT : gaz_engine {
     bool timing = false;
     std::vector<hipEvent_t> ev;      // every timing event (owned)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_tree, ev_eval;   // brackets around tree steps / evaluator passes
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fused;           // brackets around fused tree + trunk launches
     int64_t n_waves_total = 0, n_waves_timed = 0;
     static constexpr int TIMING_STRIDE = 8;
     std::vector<void*> allocs;
@@ -409,7 +410,40 @@ template <class G> struct EngineT : gaz_engine {
     }
     void launch_wave() { launch_wave(stream, 0, E.n_games); }
 
+    // ---- fused tree + trunk launch (resnet.hip k_wave_trunk): Connect4 PUCT with the whole-trunk ResNet evaluator, no evaluation
+    // cache (its probe reads rows other teams are writing).  GAZ_FUSE_WAVE=0 -> separate launches.
+    uint32_t* d_done = nullptr; uint32_t fuse_epoch = 0; int fuse_state = -1;     // -1 not decided, 0 off, 1 on
+    bool can_fuse() {
+        if (fuse_state >= 0) return fuse_state == 1;
+        fuse_state = 0;
+        static const bool off = getenv("GAZ_FUSE_WAVE") && atoi(getenv("GAZ_FUSE_WAVE")) == 0;
+        typedef typename PuctVariant<G>::type GP;
+        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || cfg.search != GAZ_SEARCH_PUCT || E.cache || E.compact || !eval || !eval->supports_split()) return false;
+        if (getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
+        if (dalloc(&d_done, (size_t)E.n_games)) return false;
+        fuse_state = 1;
+        return true;
+    }
+
     int one_wave(bool with_eval) {
+        if (with_eval && eval && can_fuse()) {
+            const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
+            const void* plan = eval->trunk_plan(E.nn_in, E.n_games, 0, d_done, fuse_epoch + 1);
+            if (plan) {
+                hipEvent_t e0 = 0, e1 = 0, e2 = 0;
+                if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
+                DevParams<G> Ef = E; Ef.done_flag = d_done; Ef.wave_epoch = ++fuse_epoch;
+                launch_wave_trunk_c4(stream, &Ef, 0, E.n_games, plan);
+                if (timing) hipEventRecord(e1, stream);
+                eval->forward_heads(stream, E.nn_policy, E.nn_value, E.n_games, 0);
+                if (timing) {       // the fused kernel is booked as evaluator time; tree time is what it hides
+                    hipEventRecord(e2, stream); ev_eval.push_back({e0, e2}); n_waves_timed++;
+                    ev_fused.push_back({e0, e1});
+                }
+                n_waves_total++;
+                return 0;
+            }
+        }
         // timing brackets on every TIMING_STRIDE-th wave only: an event record is a barrier packet of its own (~5 us between two
         // kernels; five of them per wave were 4 % of the wave they measured)
         const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
@@ -649,6 +683,7 @@ template <class G> struct EngineT : gaz_engine {
         memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
         out[9] = (uint64_t)n_waves_total; memcpy(&out[10], c + 8, 8);
         out[11] = pipeline_ready ? (uint64_t)n_grp : 0;
+        out[12] = fuse_state == 1 ? 1 : 0;
         return check_device_error();
     }
 
@@ -657,7 +692,7 @@ template <class G> struct EngineT : gaz_engine {
     int timing_reset(int enable) override {
         HIP_OK(hipStreamSynchronize(stream));
         for (hipEvent_t e : ev) hipEventDestroy(e);
-        ev.clear(); ev_tree.clear(); ev_eval.clear(); n_waves_total = 0; n_waves_timed = 0; timing = enable != 0;
+        ev.clear(); ev_tree.clear(); ev_eval.clear(); ev_fused.clear(); n_waves_total = 0; n_waves_timed = 0; timing = enable != 0;
         if (eval) eval->timing_reset();
         return 0;
     }
@@ -749,7 +784,10 @@ template <class G> struct EngineT : gaz_engine {
         const int n_launch = can_pipeline() ? E.n_games / n_grp : E.n_games;
         double f = 0; const char* k = eval ? eval->dominant_kernel(n_launch, &f) : "";
         if (eval && can_pipeline()) { double fa = 0; eval->dominant_kernel(E.n_games, &fa); f = fa / n_grp; }
-        if (name && cap > 0) { strncpy(name, k, cap - 1); name[cap - 1] = 0; }
+        std::string label = k;
+        if (fuse_state == 1) label = "k_wave_trunk = " + label + " FUSED with the PUCT tree step of the same wave (one launch: tree blocks first, trunk workgroups start on the "
+                                     "boards whose games are done; the launch duration therefore includes the part of the tree step it could not hide)";
+        if (name && cap > 0) { strncpy(name, label.c_str(), cap - 1); name[cap - 1] = 0; }
         if (flops) *flops = f;
         return 0;
     }
@@ -761,6 +799,7 @@ template <class G> struct EngineT : gaz_engine {
         if (ms_tree) *ms_tree = t; if (ms_eval) *ms_eval = e;
         double d = 0; int64_t nd = 0;
         if (eval) eval->timing_get(&d, &nd);
+        for (auto& pr : ev_fused) { float a = 0; hipEventElapsedTime(&a, pr.first, pr.second); d += a; nd++; }
         if (ms_dom) *ms_dom = d; if (n_dom) *n_dom = nd; if (n_waves) *n_waves = n_waves_timed;
         return 0;
     }

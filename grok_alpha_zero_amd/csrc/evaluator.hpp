@@ -25,6 +25,10 @@ struct Evaluator {
     virtual int round_rows() const { return 0; }                  // positions one full round of the trunk kernel's tiles covers
     virtual void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int p0) { (void)s; (void)in; (void)n; (void)timing; (void)p0; }
     virtual void forward_heads(hipStream_t s, float* policy, float* value, int n, int p0) { (void)s; (void)policy; (void)value; (void)n; (void)p0; }
+    // fused tree + trunk launch (fused.hip): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
+    // planes of board b are valid once ready[b] == epoch.  Null = this evaluator / configuration cannot be fused.
+    virtual const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) { (void)in; (void)n; (void)p0; (void)ready; (void)epoch; return nullptr; }
+    virtual void note_fused_launch(hipEvent_t e0, hipEvent_t e1) { (void)e0; (void)e1; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
@@ -76,6 +80,9 @@ struct HashEvaluator : Evaluator {
 };
 
 Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err);
+// fused.hip: ONE launch = the PUCT tree step of Connect4 games [g0, g1) (16-lane teams) + the trunk kernel of their leaf rows.
+// dev_params: DevParams<TeamGame<GAME_C4>> by value; plan: what Evaluator::trunk_plan returned.  false = not launched.
+bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
 
 inline Evaluator* make_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err) {
     if (cfg.evaluator == GAZ_EVAL_HASH) return new HashEvaluator(H * W * C, A, cfg.hash_salt);

@@ -69,7 +69,21 @@ template <class G> struct DevParams {
     const double* puct_table;  // [PUCT_TABLE_N][2]: sqrt(pv), c_init + ln((pv + c_base + 1) / c_base)
     unsigned long long* prof;  // diagnostic (GAZ_TREE_PROF=1): [n_games][8] shader-clock cycles per phase of the PUCT kernel, else null
     int32_t* error;            // first error code, 0 = none
+    // fused tree + trunk launch (fused.hip): a game's team publishes "my leaf row of this wave is in memory" so that the trunk
+    // workgroups of the SAME launch can start on their boards while slower games are still searching.  Null = plain launches.
+    uint32_t* done_flag;       // [n_games] epoch of the last launch that finished the game's tree step
+    uint32_t wave_epoch;
 };
+
+// stores / loads that meet at the device's point of coherence (no L1 / per-XCD L2 copy): used for the leaf rows and the done flags
+// a fused launch hands from a tree team to a trunk workgroup on another CU / XCD while both are running
+GAZ_DEV void store_coherent(int* p, int v) {
+#ifdef GAZ_HOST_EMU
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
 
 // phase accounting of the PUCT kernel: 0 consume, 1 select, 2 expand_pre, 3 probe, 4 expand_post (hit), 5 terminal backup, 6 whole launch, 7 launches
 #ifdef GAZ_HOST_EMU
@@ -202,7 +216,7 @@ template <class G> GAZ_DEV int terminal_probe(const int8_t* board, const uint8_t
 // Connect4.py:329-346 (incl. the plane-0 overwrite once >= 4 moves were played), Gomoku.py:175-177,
 // Tictactoe.py:231-235.  hist3 = last three actions newest first, n_hist = len(action_history).
 template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_player, const uint8_t* hist3, int n_hist,
-                                             int8_t* out) {
+                                             int8_t* out, bool coherent = false) {
     if (G::ID == GAME_C4) {
         int max_length = n_hist - 1; if (max_length > 3) max_length = 3; if (max_length < 0) max_length = 0;
         int rem[3] = {-1, -1, -1};
@@ -231,7 +245,8 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
             if (max_length < 1) p2 = 0;
             if (max_length < 2) p1 = 0;
             char4 v; v.x = p0; v.y = p1; v.z = p2; v.w = b;
-            *reinterpret_cast<char4*>(out + c * 4) = v;
+            if (coherent) { int w; memcpy(&w, &v, 4); store_coherent(reinterpret_cast<int*>(out + c * 4), w); }
+            else *reinterpret_cast<char4*>(out + c * 4) = v;
         }
     } else {
         for (int c = tlane<G>(); c < G::HW; c += G::TEAM) {
@@ -398,7 +413,7 @@ template <class G> GAZ_DEV bool root_pre(const DevParams<G>& E, int g, GameState
         wave_sync();
         return false;
     }
-    encode_input<G>(S.board, -gs.next_player, h3, gs.n_hist, E.nn_in + (size_t)g * (G::HW * G::C));
+    encode_input<G>(S.board, -gs.next_player, h3, gs.n_hist, E.nn_in + (size_t)g * (G::HW * G::C), E.done_flag != nullptr);
     wave_sync();
     return true;
 }
@@ -593,7 +608,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     }
     copy_board<G>(nd.board(), S.board);
     uint8_t h3[3] = {(uint8_t)action, ph.hist3[0], ph.hist3[1]};
-    encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C));
+    encode_input<G>(S.board, mover, h3, (int)ph.n_hist + 1, E.nn_in + (size_t)g * (G::HW * G::C), E.done_flag != nullptr);
     // park the path for expand_post
     PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
     for (int d = tlane<G>(); d <= depth; d += G::TEAM) gp[d] = S.path[d];
@@ -1019,16 +1034,26 @@ template <class G, class T> GAZ_DEV void copy_state_words(T* dst, const T* src) 
     for (int i = tlane<G>(); i < (int)(sizeof(T) / 4); i += G::TEAM) d[i] = s[i];
 }
 
+// fused launch: the team's leaf row (coherent stores, encode_input) has reached memory -> publish the epoch
+template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g) {
+#ifndef GAZ_HOST_EMU
+    if (!E.done_flag) return;
+    __builtin_amdgcn_s_waitcnt(0);                  // vmcnt(0): every store of this wave — the leaf row included — has been acknowledged
+    if (tlane<G>() == 0) store_coherent(reinterpret_cast<int*>(E.done_flag + g), (int)E.wave_epoch);
+#endif
+}
+
 template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {
     GameState<G>* gsG = &E.games[g];
     TreeState* tsG = E.trees + (size_t)g * 2;
-    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); return; }
+    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); publish_done<G>(E, g); return; }
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.ts[0], &tsG[0]); copy_state_words<G>(&L.ts[1], &tsG[1]);
     wave_sync();
     game_step_body<G>(E, g, S, L.gs, L.ts);
     wave_sync();
     copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(&tsG[0], &L.ts[0]); copy_state_words<G>(&tsG[1], &L.ts[1]);
+    publish_done<G>(E, g);
     GAZ_PROF(6, tw0);
 }
 

@@ -24,6 +24,7 @@
 #include "netops.hpp"
 #include "resblock.hpp"
 #include "trunk.hpp"
+#include "puct_core.hpp"      // the fused tree + trunk launch at the end of this file steps the games with the tree kernel's device code
 
 namespace gaz {
 
@@ -548,6 +549,35 @@ struct ResNetEvaluator : Evaluator {
     bool supports_row_base() const override { return true; }
     bool head_features(const float** p, const float** v, int* pr, int* vr) override { *p = pfeat; *v = vfeat; *pr = HW * 8; *vr = HW * 8; return true; }
     bool supports_split() const override { return fused && trunk && trunk_whole && blocks > 0 && HW <= 128; }
+    // kernel arguments + grid of the whole-trunk launch for rows [p0, p0 + n) (k_trunk_mix / k_trunk with stem and heads inside)
+    bool make_trunk_plan(const int8_t* in, int n, int p0, TrunkLaunchPlan& P) {
+        if (!loaded || !supports_split()) return false;
+        const int M = n * HW;
+        TrunkArgs& r = P.args; memset(&r, 0, sizeof(r));
+        r.xin = this->X + (size_t)p0 * HW * 128; r.xout = this->X2 + (size_t)p0 * HW * 128; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
+        r.tile_rows = (128 / HW) * HW; r.stamps = nullptr;
+        r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
+        r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
+        r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"];
+        r.p_feat = this->pfeat + (size_t)p0 * HW * 8; r.v_feat = this->vfeat + (size_t)p0 * HW * 8;
+        int nwg = (M + r.tile_rows - 1) / r.tile_rows;
+        bool mix = false;
+        if (trunk_mix && 96 / HW >= 1 && 96 / HW < 128 / HW) {    // whole rounds of 128-row tiles, the rest in 96-row tiles (k_trunk_mix)
+            const int slots = 2 * n_cus, bb = 128 / HW, sb = 96 / HW;
+            const int nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
+            const double cost_mix = nb / slots + 0.78 * ((ns + slots - 1) / slots), cost_big = (nwg + slots - 1) / slots;
+            if (cost_mix < cost_big) { mix = true; r.n_big = nb; r.small_rows = sb * HW; nwg = nb + ns; }
+        }
+        P.nwg = nwg; P.mix = mix; P.lds_bytes = (unsigned)trunk_lds_bytes(128);
+        return true;
+    }
+    TrunkLaunchPlan fused_plan;
+    const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) override {
+        if (!trunk_m16 || !make_trunk_plan(in, n, p0, fused_plan)) return nullptr;
+        fused_plan.args.ready = ready; fused_plan.args.epoch = epoch;
+        return &fused_plan;
+    }
+    void note_fused_launch(hipEvent_t e0, hipEvent_t e1) override { tev.push_back(e0); tev.push_back(e1); }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         forward_trunk(s, in, n, timing, p0);
@@ -1043,6 +1073,55 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
+}
+
+}  // namespace gaz
+
+// =====================================================================================================================
+// Fused tree + trunk launch — ONE launch per simulation wave for the headline path: the PUCT tree step of every Connect4 game AND the trunk kernel
+// (stem + all residual blocks + the heads' first convolution) of the leaf rows those games write.
+//
+// Why: the tree kernel's duration is its slowest games (a dependent chain of HBM round trips per simulation: ~27 us for the mean
+// game, 65 us for the launch), and while it runs the matrix cores idle; launched as separate kernels the trunk cannot start before
+// the last game is done.  Here the first blocks of the grid are tree blocks (4 waves x four 16-lane teams = 16 games each) and the
+// rest are trunk workgroups; workgroups are dispatched in index order, so every tree block is resident before any trunk workgroup
+// exists, and a trunk workgroup only waits (sleeping) for the done flags of ITS three boards: the trunk starts on the games that are
+// ready while the slow ones finish.  A tree block shares its CU with one trunk workgroup; when it exits, the second one moves in.
+// The hand-over of a leaf row from a team to a workgroup on another CU / XCD inside a running kernel goes through system-scope
+// stores and loads (puct_core.hpp store_coherent / publish_done, trunk.hpp TrunkArgs::ready) — no cache flush, no atomics on the tree.
+// Results are bit-identical to separate launches (same device functions; tests/test_evaluator_gpu.py).
+namespace gaz {
+
+typedef TeamGame<GAME_C4> GP4;
+
+template <bool MIX> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+    if ((int)blockIdx.x < n_tree_blocks) {
+        // ---- tree role: wave w of the block steps games [(4 b + w) PER, +PER); its scratch lives in the launch's dynamic LDS
+        constexpr int PER = WAVE / GP4::TEAM, NT = (TR_THREADS / WAVE) * PER;
+        extern __shared__ uint4 lds[];
+        Scratch<GP4>* S = reinterpret_cast<Scratch<GP4>*>(lds);
+        PuctLocal<GP4>* L = reinterpret_cast<PuctLocal<GP4>*>(S + NT);
+        static_assert(NT * (sizeof(Scratch<GP4>) + sizeof(PuctLocal<GP4>)) <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
+        const int w = threadIdx.x >> 6, t = team_in_wave<GP4>(), i = w * PER + t;
+        const int g = g0 + ((int)blockIdx.x * (TR_THREADS / WAVE) + w) * PER + t;
+        if (g < g1) game_step<GP4>(E, g, S[i], L[i]);
+        return;
+    }
+    // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid
+    const int bid = (int)blockIdx.x - n_tree_blocks;
+    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows);
+    else trunk_tile<2, 2, 8, true, true, false, true>(a, (long)bid * a.tile_rows, a.tile_rows);
+}
+
+bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {
+    if (!plan || !dev_params) return false;
+    const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
+    const DevParams<GP4>& E = *static_cast<const DevParams<GP4>*>(dev_params);
+    constexpr int GAMES_PER_BLOCK = (TR_THREADS / WAVE) * (WAVE / GP4::TEAM);
+    const int n_tree = (g1 - g0 + GAMES_PER_BLOCK - 1) / GAMES_PER_BLOCK;
+    if (P.mix) hipLaunchKernelGGL(k_wave_trunk<true>, dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    else hipLaunchKernelGGL(k_wave_trunk<false>, dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    return true;
 }
 
 }  // namespace gaz

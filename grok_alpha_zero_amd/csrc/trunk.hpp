@@ -31,10 +31,16 @@ struct TrunkArgs {
     unsigned long long* stamps;                   // diagnostic (GAZ_TRUNK_STAMPS, tools/trunk_stamps.py): [workgroup][128] or null
     // STEM: the stem convolution (k_stem_mfma's operands) computed straight into the images instead of reading xin
     const int8_t* planes; const uint4* stem_frag; const float* stem_shift;        // [M][4] int8; [6 k-steps][2][128] x 8 bf16 (hi | lo); [128]
+    // fused tree + trunk launch (fused.hip): board b's planes are valid once ready[b] has reached `epoch` (written by the tree team
+    // of game b in this very launch); null = the planes were complete before the launch
+    const unsigned* ready; unsigned epoch;
     // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
     const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
 };
+
+// what ResNetEvaluator::forward_trunk launches, as data: used by the fused tree + trunk launch (fused.hip)
+struct TrunkLaunchPlan { TrunkArgs args; int nwg; int mix; unsigned lds_bytes; };
 
 __device__ __forceinline__ float gelu_as(float v) {         // x * Phi(x), Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8)
     const float x = fabsf(v) * 0.70710678118654752440f;
@@ -150,6 +156,11 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         const int row = lrow[tm], cslot = (wn * TN + tn) * 4 + j;
         return row * 256 + (swz_slot<M16>(cslot, row) << 4) + lhi * 8;
     };
+    if (STEM && a.ready) {                          // wait for the tree teams of this tile's boards (see TrunkArgs::ready)
+        const long b = m0 / HW + tid;
+        if (tid < tile_rows / HW && b * HW < a.M)
+            while ((int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) __builtin_amdgcn_s_sleep(16);
+    }
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
     TR_STAMP(1);
 
@@ -177,7 +188,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                     const int tap = ks * 4 + lhi * 2 + h;
                     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                     int packed = 0;
-                    if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u)) packed = in32[gr + dy * a.W + dx];
+                    if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u))   // fused launch: the row was written during this launch -> read it where it was written to
+                        packed = a.ready ? __hip_atomic_load(in32 + (gr + dy * a.W + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : in32[gr + dy * a.W + dx];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) pl[h * 4 + c] = (int)(int8_t)((packed >> (8 * c)) & 0xFF);
                 }

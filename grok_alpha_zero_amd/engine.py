@@ -295,7 +295,7 @@ class SelfPlayEngine:
         out = (C.c_uint64 * 16)()
         self._ck(self.L.gaz_engine_get_stats(self.h, out))
         s = [int(x) for x in out]
-        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11])
+        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11], fused_wave=s[12])
 
     def drain_finished(self, max_records=None):
         """Finished games as dicts: actions, policies [T,A], q, z, values (=0.5(z+q), Self_Play.py:165-172),
@@ -336,8 +336,8 @@ class SelfPlayEngine:
         self._ck(self.L.gaz_engine_timing_reset(self.h, int(enable)))
 
     def dominant_kernel(self):
-        buf = C.create_string_buffer(256); fl = C.c_double()
-        self._ck(self.L.gaz_engine_dominant_kernel(self.h, buf, 256, C.byref(fl)))
+        buf = C.create_string_buffer(1024); fl = C.c_double()
+        self._ck(self.L.gaz_engine_dominant_kernel(self.h, buf, 1024, C.byref(fl)))
         return buf.value.decode(), fl.value
 
     def timing(self):

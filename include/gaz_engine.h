@@ -187,7 +187,8 @@ int gaz_engine_record_layout(gaz_engine* h, gaz_record_layout* out);
 int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int32_t* n_out);
 int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]);  /* [0..5] game_stats, [6] evaluator calls, [7] simulations,
                                                                [8] plies played (= positions, incl. games in progress), [9] waves launched,
-                                                               [10] evaluations answered by the evaluation cache, [11] groups of the group pipeline (0 = off) */
+                                                               [10] evaluations answered by the evaluation cache, [11] groups of the group pipeline (0 = off),
+                                                               [12] 1 = tree step and trunk kernel run as ONE fused launch */
 int gaz_engine_synchronize(gaz_engine* h);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */

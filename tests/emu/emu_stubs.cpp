@@ -6,4 +6,5 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config&, int, int, int, int, s
     *err = "the ResNet evaluator needs the HIP build";
     return nullptr;
 }
+bool launch_wave_trunk_c4(hipStream_t, const void*, int, int, const void*) { return false; }
 }
