@@ -314,6 +314,19 @@ def main():
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     tm = eng.timing()
     kname, kflops = eng.dominant_kernel()
+    fused = bool(eng.stats().get("fused_wave"))
+    tm_fused = None
+    if fused and use_net:
+        # The headline segment ran the tree step and the trunk kernel as ONE launch (k_wave_trunk): its duration includes the part of
+        # the tree step it could not hide, so it does not price the MFMA kernel.  Time the trunk kernel on its own in a second
+        # segment of this run: same engine, same games, tree step and trunk launched separately (results are bit-identical).
+        tm_fused, kname_fused = tm, kname
+        eng.set_fused_wave(False)
+        eng.timing_reset(True)
+        eng.run_waves(args.waves_per_step); eng.synchronize()
+        tm = eng.timing()
+        kname, kflops = eng.dominant_kernel()
+        eng.set_fused_wave(True)
     eng.timing_reset(False)
     total = reduce_stats(delta, world)                      # the one collective of the path: counters only
     positions, games, evals, sims, hits = (int(x) for x in total)
@@ -342,6 +355,14 @@ def main():
                         traffic_source=(f"{traffic_src}: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this command, "
                                         "not measured in this run") if traffic_src else None,
                         kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+            if tm_fused is not None and tm_fused["n_dominant"] > 0:
+                f_ms = tm_fused["ms_dominant"] / tm_fused["n_dominant"]
+                roof["measured_in"] = (f"a second timed segment of this run ({args.waves_per_step} waves, HIP events on every 8th) with the tree step and the "
+                                       "trunk launched as separate kernels; the headline segment runs them as ONE launch, see fused_launch")
+                roof["fused_launch"] = dict(kernel=kname_fused, avg_launch_us=f_ms * 1e3, launches=int(tm_fused["n_dominant"]),
+                                            frac_if_priced_as_mfma_only=kflops / (f_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                            note="duration of tree step + trunk in one launch during the headline segment: the tree step's "
+                                                 "slowest games (a latency-bound pointer chase) are partly hidden behind the trunk's first workgroups")
         label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[args.config]
         out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
                    value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -356,8 +377,10 @@ def main():
                                evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=sims / dt,
                                eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
                                eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
+                               fused_tree_and_trunk_launch=fused,
                                ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
-                               ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1)),
+                               ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1),
+                               per_wave_note=("tree / evaluator ms per wave come from the unfused timing segment" if tm_fused is not None else None)),
                    roofline=roof)
 
     # ---- extra legs (never the headline value) -------------------------------------------------------------------------

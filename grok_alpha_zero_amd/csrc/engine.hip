@@ -221,6 +221,7 @@ struct gaz_engine {
     virtual int start_search() = 0;
     virtual int set_hyperparams(const gaz_search_hyperparams*) = 0;
     virtual int read_head_features(int, float*, float*, int32_t*, int32_t*) = 0;
+    virtual int set_fused_wave(int) = 0;
     virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
 
@@ -425,8 +426,11 @@ template <class G> struct EngineT : gaz_engine {
         return true;
     }
 
+    bool fuse_enabled = true;
+    int set_fused_wave(int on) override { fuse_enabled = on != 0; return 0; }
+
     int one_wave(bool with_eval) {
-        if (with_eval && eval && can_fuse()) {
+        if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
             const void* plan = eval->trunk_plan(E.nn_in, E.n_games, 0, d_done, fuse_epoch + 1);
             if (plan) {
@@ -683,7 +687,7 @@ template <class G> struct EngineT : gaz_engine {
         memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
         out[9] = (uint64_t)n_waves_total; memcpy(&out[10], c + 8, 8);
         out[11] = pipeline_ready ? (uint64_t)n_grp : 0;
-        out[12] = fuse_state == 1 ? 1 : 0;
+        out[12] = (fuse_state == 1 && fuse_enabled) ? 1 : 0;
         return check_device_error();
     }
 
@@ -785,7 +789,7 @@ template <class G> struct EngineT : gaz_engine {
         double f = 0; const char* k = eval ? eval->dominant_kernel(n_launch, &f) : "";
         if (eval && can_pipeline()) { double fa = 0; eval->dominant_kernel(E.n_games, &fa); f = fa / n_grp; }
         std::string label = k;
-        if (fuse_state == 1) label = "k_wave_trunk = " + label + " FUSED with the PUCT tree step of the same wave (one launch: tree blocks first, trunk workgroups start on the "
+        if (fuse_state == 1 && fuse_enabled) label = "k_wave_trunk = " + label + " FUSED with the PUCT tree step of the same wave (one launch: tree blocks first, trunk workgroups start on the "
                                      "boards whose games are done; the launch duration therefore includes the part of the tree step it could not hide)";
         if (name && cap > 0) { strncpy(name, label.c_str(), cap - 1); name[cap - 1] = 0; }
         if (flops) *flops = f;
@@ -857,6 +861,7 @@ int gaz_engine_set_search_params(gaz_engine* h, int32_t run_iterations, int32_t 
 int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(stop); }
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
+int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on) { return h->set_fused_wave(on); }
 int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p, float* v, int32_t* p_row, int32_t* v_row) { return h->read_head_features(n, p, v, p_row, v_row); }
 int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,
                            uint8_t* legal, int32_t* winner, int8_t* input, int32_t* terminal, const float* policy_in, float* policy_out) {

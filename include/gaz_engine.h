@@ -26,6 +26,7 @@
  *                                 MCTS_Gumbel.update_hyperparams(m, c_visit, c_scale)  MCTS_Gumbel.py:186-210
  *   gaz_engine_probe_rules     the Game plugin's static *_MCTS functions          Guide.py:135-283, Game_Tester.py:297-405
  *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
+ *   gaz_engine_set_fused_wave     (scheduling switch; no reference counterpart: Client_Server.py's server loop is what it replaces)
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  *   gaz_engine_read_head_features  intermediate tensors of that probe (numerics tests)  Connect4/Build_Model.py:41-47,62-66
  */
@@ -190,6 +191,11 @@ int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]);  /* [0..5] game_stats
                                                                [10] evaluations answered by the evaluation cache, [11] groups of the group pipeline (0 = off),
                                                                [12] 1 = tree step and trunk kernel run as ONE fused launch */
 int gaz_engine_synchronize(gaz_engine* h);
+
+/* Connect4 PUCT with the ResNet evaluator runs the tree step and the trunk kernel of a wave as ONE launch (k_wave_trunk: the trunk
+ * starts on the boards whose games are done while the slow games still search); on = 0 launches them separately (same results bit
+ * for bit; bench.py uses it to time the trunk kernel on its own).  Scheduling only. */
+int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);

@@ -339,3 +339,28 @@ def test_resnet_evaluator_matches_bf16_faithful_reference_end_to_end(blocks, n, 
     m = _faithful_metrics(lambda head: Connect4Net(blocks, seed=11, policy_head=head).eval().randomize_bn(7), blocks, x, "1", monkeypatch)
     print("end-to-end faithful metrics", blocks, m)
     assert m["prob_max"] <= 6e-2 and m["value_max"] <= 0.1 and m["p_feat_mean"] <= 3e-2 and m["v_feat_mean"] <= 3e-2, m
+
+
+def test_fused_tree_and_trunk_launch_gives_identical_games():
+    """k_wave_trunk (resnet.hip): the PUCT tree step of every Connect4 game and the trunk kernel of their leaf rows in ONE launch — tree
+    blocks first, each trunk workgroup waiting only for the done flags of its own three boards, the leaf rows handed over through
+    system-scope stores / loads while both roles are running.  Scheduling only: the finished games must equal, bit for bit, those of
+    separate launches (gaz_engine_set_fused_wave(0)) — every record, including the evaluator-call counts per move."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=5).eval().export_engine_weights()
+    got = []
+    for fused in (True, False):
+        eng = SelfPlayEngine("Connect4", 1600, 24, 14, 4, 3, 2.5, 0.5, seed=19, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192)
+        eng.load_weights(w)
+        eng.set_fused_wave(fused)
+        eng.run_waves(260); eng.run_waves(140); eng.synchronize()
+        st = eng.stats()
+        assert st["fused_wave"] == int(fused)
+        got.append({(r["slot"], r["game_seq"]): r for r in eng.drain_finished(8192)})
+        eng.close()
+    a, b = got
+    assert len(a) > 1600 and set(a) == set(b)
+    for k in a:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
