@@ -5,7 +5,7 @@
 // un-popped legal actions in descending-prior order.
 //
 // Here: one flat arena per (game, tree); a node is a fixed-size record holding a 32-byte header, then
-// structure-of-arrays blocks over its children — N u32[APAD] | W f32[APAD] | P f32[APAD] |
+// structure-of-arrays blocks over its children — P f32[APAD] | N u32[APAD] | W f32[APAD] |
 // child i32[APAD] | action u8[APAD] — then the node's int8 board.  Children are stored in descending-prior
 // order, so "pop the next legal action" (MCTS.py:437) is slot n_children and the reference's invariant
 // best_index <= len(children) (MCTS.py:217) holds by construction.  A select step touches one record
@@ -34,10 +34,12 @@ struct NodeHdr {          // 32 bytes
 static_assert(sizeof(NodeHdr) == 32, "NodeHdr must be 32 bytes");
 
 template <class G> struct NodeLayout {
-    static constexpr int OFF_N = 32;
+    // P first: a backup updates N[s] and W[s] of every node on the path, and with N | W behind the 32-byte header + P block the two
+    // words of a Connect4 node share one 64-byte sector (bytes 64..127) instead of straddling two
+    static constexpr int OFF_P = 32;
+    static constexpr int OFF_N = OFF_P + 4 * G::APAD;
     static constexpr int OFF_W = OFF_N + 4 * G::APAD;
-    static constexpr int OFF_P = OFF_W + 4 * G::APAD;
-    static constexpr int OFF_CHILD = OFF_P + 4 * G::APAD;
+    static constexpr int OFF_CHILD = OFF_W + 4 * G::APAD;
     static constexpr int OFF_ACT = OFF_CHILD + 4 * G::APAD;
     static constexpr int OFF_BOARD = OFF_ACT + G::APAD;
     static constexpr int SIZE = (OFF_BOARD + G::BPAD + 31) / 32 * 32;

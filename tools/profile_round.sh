@@ -14,15 +14,15 @@ echo "== bench gumbel"; timeout -k 10 300 python bench.py --config gumbel --no-c
 echo "== bench gomoku"; timeout -k 10 300 python bench.py --config gomoku --no-cpu-baseline > $out/bench_gomoku.json 2> $out/bench_gomoku.err || exit 1
 fi
 echo "== rocprofv3 --kernel-trace --stats (headline command, 2 steps)"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --cache-leg 0 > $out/stats.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/stats.log 2>&1 || exit 1
 echo "== rocprofv3 --pmc FETCH_SIZE (evaluator probe + 40 waves of the engine)"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_f.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_f -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/pmc_f.log 2>&1 || exit 1
 echo "== rocprofv3 --pmc WRITE_SIZE"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_w.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_w -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/pmc_w.log 2>&1 || exit 1
 find $out -name "*.csv" | head -20
 echo done
 echo "== rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (MFMA utilisation)"
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_m -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_m.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_m -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/pmc_m.log 2>&1 || exit 1
 echo "== rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out/pmc_l -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 > $out/pmc_l.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out/pmc_l -o run -- python bench.py --steps 1 --warmup 0 --waves-per-step 40 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/pmc_l.log 2>&1 || exit 1
 echo done2
