@@ -314,7 +314,9 @@ template <class G> struct EngineT : gaz_engine {
         }
         // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms; with the evaluation cache a hit is such a simulation too and 8 pays
         // (small boards; a Gomoku simulation is ten times as long and 8 only stretches the launch)
-        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : ((cfg.eval_cache_log2 > 0 && G::A <= 64) ? 8 : 4);
+        // (round 2) with the fused tree + trunk launch the tail of the tree step hides behind the trunk: 12 pays there (69.6 k vs 67.9 k)
+        const bool fusable = G::ID == GAME_C4 && cfg.search == GAZ_SEARCH_PUCT && cfg.evaluator == GAZ_EVAL_RESNET;
+        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : ((cfg.eval_cache_log2 > 0 && G::A <= 64) ? (fusable ? 12 : 8) : 4);
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);
@@ -396,6 +398,7 @@ template <class G> struct EngineT : gaz_engine {
     }
 
     hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
+    static constexpr size_t MAX_TIMING_EVENTS = 1 << 16;            // a timed run of any length holds at most this many events
 
     void launch_wave(hipStream_t st, int g0, int g1) {
         if (cfg.search == GAZ_SEARCH_GUMBEL) { GAZ_LAUNCH(k_wave_gumbel<G>, g1 - g0, WAVE, st, E, g0, g1); return; }
@@ -419,7 +422,10 @@ template <class G> struct EngineT : gaz_engine {
         fuse_state = 0;
         static const bool off = getenv("GAZ_FUSE_WAVE") && atoi(getenv("GAZ_FUSE_WAVE")) == 0;
         typedef typename PuctVariant<G>::type GP;
-        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || cfg.search != GAZ_SEARCH_PUCT || E.cache || E.compact || !eval || !eval->supports_split()) return false;
+        // with the evaluation cache too (measured 67.5 k vs 64.3 k positions/s): a team's probe reads its OWN row, and the table is
+        // written by k_cache_insert between launches as before.  GAZ_FUSE_CACHE=0 -> separate launches when the cache is on
+        static const bool with_cache = !(getenv("GAZ_FUSE_CACHE") && atoi(getenv("GAZ_FUSE_CACHE")) == 0);
+        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || cfg.search != GAZ_SEARCH_PUCT || (E.cache && !with_cache) || E.compact || !eval || !eval->supports_split()) return false;
         if (getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
         if (dalloc(&d_done, (size_t)E.n_games)) return false;
         fuse_state = 1;
@@ -431,7 +437,7 @@ template <class G> struct EngineT : gaz_engine {
 
     int one_wave(bool with_eval) {
         if (with_eval && eval && fuse_enabled && can_fuse()) {
-            const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
+            const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
             const void* plan = eval->trunk_plan(E.nn_in, E.n_games, 0, d_done, fuse_epoch + 1);
             if (plan) {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
@@ -440,6 +446,7 @@ template <class G> struct EngineT : gaz_engine {
                 launch_wave_trunk_c4(stream, &Ef, 0, E.n_games, plan);
                 if (timing) hipEventRecord(e1, stream);
                 eval->forward_heads(stream, E.nn_policy, E.nn_value, E.n_games, 0);
+                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
                 if (timing) {       // the fused kernel is booked as evaluator time; tree time is what it hides
                     hipEventRecord(e2, stream); ev_eval.push_back({e0, e2}); n_waves_timed++;
                     ev_fused.push_back({e0, e1});
@@ -450,7 +457,7 @@ template <class G> struct EngineT : gaz_engine {
         }
         // timing brackets on every TIMING_STRIDE-th wave only: an event record is a barrier packet of its own (~5 us between two
         // kernels; five of them per wave were 4 % of the wave they measured)
-        const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0;
+        const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
         launch_wave();
