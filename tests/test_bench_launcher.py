@@ -85,3 +85,19 @@ def test_cpu_baseline_runs_workers_against_one_batching_server(oracle):
     assert r["kind"] == "port" and r["cores"] == bench.host_cores() <= len(os.sched_getaffinity(0)) and r["value"] > 0
     assert r["mean_batch"] > 1.0 or r["cores"] == 1                # requests of several workers really share a forward pass
     assert "whole games" in r["sample"]
+
+
+def test_driver_form_torch_distributed_run(emu_lib):
+    """The form the round-end driver uses for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — the ranks already exist (RANK / WORLD_SIZE set by the launcher), bench.py must
+    run the body in each and rank 0 print the one line with n_gpus = N."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--emu-lib", emu_lib] + SMALL
+    p = subprocess.run(cmd, env=_clean_env(), capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and len(r["detail"]["positions_per_rank"]) == 2 and all(x > 0 for x in r["detail"]["positions_per_rank"])
