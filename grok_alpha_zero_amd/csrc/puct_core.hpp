@@ -107,7 +107,8 @@ template <class G> struct Scratch {   // per-wave LDS
     float aux[G::APAD];
     double gam[G::APAD];
     PathEnt path[PathCap<G>::V];
-    uint32_t node[(NodeLayout<G>::OFF_BOARD + 3) / 4];   // header + child arrays of the node being scored (one HBM round trip per level)
+    alignas(16) uint32_t node[NodeLayout<G>::SIZE / 4];  // the WHOLE record of the node being scored — header, child arrays and board —
+                                                         // in one round trip of 16-byte loads per level (expand_pre takes the board from here)
     float raw[G::APAD];        // Gumbel: the RAW[] block of that node (evaluator values of the expanded children)
 };
 
@@ -264,12 +265,14 @@ template <class G> GAZ_DEV void encode_input(const int8_t* board, int current_pl
 constexpr int PUCT_TABLE_N = 16384;
 GAZ_DEV double puct_c_of(double pv, double c_init, double c_base) { return c_init + det::dlog((pv + c_base + 1.0) / c_base); }
 
-template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_actions, uint64_t parent_visits,
-                                              double c_init, double c_base, const double* table) {
-    const double pv = (double)parent_visits;
-    double s, c;
+// the two factors that depend only on the parent's visit count (table, or computed): loaded by the caller BEFORE it stages the node
+// record, so that the table's L2 round trip overlaps the record's
+GAZ_DEV void puct_factors(uint64_t parent_visits, double c_init, double c_base, const double* table, double& s, double& c) {
     if (table && parent_visits < (uint64_t)PUCT_TABLE_N) { s = table[2 * parent_visits]; c = table[2 * parent_visits + 1]; }
-    else { s = dsqrt(pv); c = puct_c_of(pv, c_init, c_base); }
+    else { const double pv = (double)parent_visits; s = dsqrt(pv); c = puct_c_of(pv, c_init, c_base); }
+}
+
+template <class G> GAZ_DEV int best_puct_slot(const NodeRef<G>& nd, int n_actions, double s, double c) {
     const uint32_t* N = nd.N(); const float* Wv = nd.W(); const float* P = nd.P();
     double best = 0.0; int bi = 0x7fffffff;
     for (int i = tlane<G>(); i < n_actions; i += G::TEAM) {
@@ -441,11 +444,14 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
     for (;;) {
         // Stage the node's header + N/W/P/child/action blocks in LDS with ONE coalesced read of the record, so a level
         // of the descent costs one dependent HBM/L2 round trip instead of three (header -> stats -> chosen child).
+        double fs, fc;
+        puct_factors(pv, E.c_init, E.c_base, E.puct_table, fs, fc);       // issued first: in flight together with the record
         {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(node_at(E, g, t, node).p);
-            constexpr int NW = (NodeLayout<G>::OFF_BOARD + 3) / 4;
+            const uint4* src = reinterpret_cast<const uint4*>(node_at(E, g, t, node).p);
+            constexpr int NQ = NodeLayout<G>::SIZE / 16;
+            static_assert(NodeLayout<G>::SIZE % 16 == 0, "records are copied in 16-byte units");
             wave_sync();
-            for (int i = tlane<G>(); i < NW; i += G::TEAM) S.node[i] = src[i];
+            for (int i = tlane<G>(); i < NQ; i += G::TEAM) reinterpret_cast<uint4*>(S.node)[i] = src[i];
             wave_sync();
         }
         NodeRef<G> nd{reinterpret_cast<uint8_t*>(S.node)};
@@ -486,7 +492,7 @@ template <class G> GAZ_DEV int puct_select(const DevParams<G>& E, int g, GameSta
             wave_sync();
             return 1;
         }
-        const int best = best_puct_slot<G>(nd, n_actions, pv, E.c_init, E.c_base, E.puct_table);
+        const int best = best_puct_slot<G>(nd, n_actions, fs, fc);
         if (best == n_children) { wave_sync(); return 0; }          // MCTS.py:217-218
         if (best > n_children) { set_error(E.error, ERR_BAD_SELECT); return -1; }
         S.path[depth].node = node; S.path[depth].slot = best; depth++;
@@ -577,7 +583,7 @@ template <class G> GAZ_DEV bool expand_pre(const DevParams<G>& E, int g, GameSta
     const int slot = tuni<G>((int)ph.n_children);
     const int action = tuni<G>((int)ps.act()[slot]);                       // popleft (MCTS.py:437)
     const int mover = -(int)tuni<G>((int)ph.player);
-    copy_board<G>(S.board, pn.board());
+    copy_board<G>(S.board, ps.board());                                 // staged: the record (board included) is already in LDS
     wave_sync();
     const int cell = landing_cell<G>(S.board, action);
     wave_sync();
@@ -626,19 +632,33 @@ template <class G> GAZ_DEV void expand_post(const DevParams<G>& E, int g, GameSt
                                             const float* policy, const float* value_p, bool fresh) {
     const int node = gs.pend_parent, slot = gs.pend_slot, idx = gs.pend_node, depth = gs.pend_depth;
     NodeRef<G> nd = node_at(E, g, t, idx);
-    if (!fresh) { copy_board<G>(S.board, nd.board()); wave_sync(); }
+    // Everything this step reads from HBM — the leaf's board, the evaluator's policy row and value, the parked path — is independent:
+    // all of it is requested before the first dependent use, one round trip instead of four in a row.
+    const float value = *value_p;
+    constexpr int PK = (G::A + G::TEAM - 1) / G::TEAM, DK = (PathCap<G>::V + G::TEAM - 1) / G::TEAM;
+    float polr[PK]; PathEnt per[DK];
+#pragma unroll
+    for (int k = 0; k < PK; ++k) { const int a = tlane<G>() + k * G::TEAM; polr[k] = a < G::A ? policy[a] : 0.0f; }
+    if (!fresh) {
+        const PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) { const int d = tlane<G>() + k * G::TEAM; if (d < depth) per[k] = gp[d]; }
+        copy_board<G>(S.board, nd.board());
+    }
+#pragma unroll
+    for (int k = 0; k < PK; ++k) { const int a = tlane<G>() + k * G::TEAM; if (a < G::A) S.aux[a] = polr[k]; }
+    if (!fresh) {
+#pragma unroll
+        for (int k = 0; k < DK; ++k) { const int d = tlane<G>() + k * G::TEAM; if (d < depth) S.path[d] = per[k]; }
+    }
+    wave_sync();
     const int n_legal = build_legal<G>(S.board, S.legal);
-    make_priors<G>(E, g, gs, ts, t, S, policy, n_legal);
+    make_priors<G>(E, g, gs, ts, t, S, S.aux, n_legal);                 // the policy row, staged in LDS
     write_children_from_scratch<G>(nd, S, n_legal);
     NodeRef<G> pn = node_at(E, g, t, node);
     if (tlane<G>() == 0) {
         nd.hdr()->n_actions = (uint8_t)n_legal; nd.hdr()->n_children = 0;
         pn.child()[slot] = idx; pn.hdr()->n_children = (uint8_t)(slot + 1);
-    }
-    const float value = *value_p;
-    if (!fresh) {
-        const PathEnt* gp = E.paths + (size_t)g * PathCap<G>::V;
-        for (int d = tlane<G>(); d < depth; d += G::TEAM) S.path[d] = gp[d];
     }
     wave_sync();
     backup<G>(E, g, t, ts, S.path, depth, -value, 1u);                 // MCTS.py:511
