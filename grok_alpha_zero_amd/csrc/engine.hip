@@ -29,12 +29,16 @@ template <class G> GAZ_DEV void wave_body(const DevParams<G>& E, int g0, int g1)
 template <class G> GAZ_KERNEL k_wave(DevParams<G> E, int g0, int g1) { wave_body<G>(E, g0, g1); }
 template <class G> GAZ_KERNEL_TEAMS k_wave_teams(DevParams<G> E, int g0, int g1) { wave_body<G>(E, g0, g1); }
 
-template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) {
-    GAZ_SHARED Scratch<G> S;
-    GAZ_SHARED GumbelLocal<G> L;
-    const int g = g0 + block_id();
-    if (g < g1) g_game_step<G>(E, g, S, L);
+template <class G> GAZ_DEV void wave_body_gumbel(const DevParams<G>& E, int g0, int g1) {
+    constexpr int PER = WAVE / G::TEAM;
+    GAZ_SHARED Scratch<G> S[PER];
+    GAZ_SHARED GumbelLocal<G> L[PER];
+    const int t = team_in_wave<G>();
+    const int g = g0 + block_id() * PER + t;
+    if (g < g1) g_game_step<G>(E, g, S[t], L[t]);
 }
+template <class G> GAZ_KERNEL k_wave_gumbel(DevParams<G> E, int g0, int g1) { wave_body_gumbel<G>(E, g0, g1); }
+template <class G> GAZ_KERNEL_TEAMS k_wave_gumbel_teams(DevParams<G> E, int g0, int g1) { wave_body_gumbel<G>(E, g0, g1); }
 
 // evaluation cache: store (state row, outputs) of every request the evaluator just answered; runs between the evaluator
 // pass and the next tree launch, so the tree kernels only ever read the table
@@ -401,9 +405,17 @@ template <class G> struct EngineT : gaz_engine {
     static constexpr size_t MAX_TIMING_EVENTS = 1 << 16;            // a timed run of any length holds at most this many events
 
     void launch_wave(hipStream_t st, int g0, int g1) {
-        if (cfg.search == GAZ_SEARCH_GUMBEL) { GAZ_LAUNCH(k_wave_gumbel<G>, g1 - g0, WAVE, st, E, g0, g1); return; }
-        // PUCT: the small boards run four games per wavefront (PuctVariant: same records, 16-lane teams); GAZ_TREE_TEAMS=0 -> one per wave
+        // the small boards run four games per wavefront (PuctVariant: same records, 16-lane teams); GAZ_TREE_TEAMS=0 -> one per wave
         typedef typename PuctVariant<G>::type GP;
+        if (cfg.search == GAZ_SEARCH_GUMBEL) {
+            static const int gteams_env = getenv("GAZ_TREE_TEAMS") ? atoi(getenv("GAZ_TREE_TEAMS")) : -1;
+            constexpr int GPER = WAVE / GP::TEAM;
+            // measured (8192 Connect4 games, n = 32, m = 7): the team build is bit-exact but SLOWER, 225 vs 185 us per launch (sequential
+            // halving keeps the four games of a wave in different phases) — opt-in only (GAZ_TREE_TEAMS=1)
+            if (GPER > 1 && gteams_env == 1) GAZ_LAUNCH(k_wave_gumbel_teams<GP>, (g1 - g0 + GPER - 1) / GPER, WAVE, st, *reinterpret_cast<const DevParams<GP>*>(&E), g0, g1);
+            else GAZ_LAUNCH(k_wave_gumbel<G>, g1 - g0, WAVE, st, E, g0, g1);
+            return;
+        }
         // measured (4096 Connect4 games): 66 vs 71 us per launch; with the evaluation cache (up to 8 evaluation-free simulations per
         // game and launch, and a wave is as slow as its slowest team) one game per wave stays faster: 60.1 k vs 56.2 k positions/s
         static const int teams_env = getenv("GAZ_TREE_TEAMS") ? atoi(getenv("GAZ_TREE_TEAMS")) : -1;
