@@ -64,6 +64,7 @@ template <class G> GAZ_KERNEL k_init_games(DevParams<G> E, int first_seq) {
     memset(&gs, 0, sizeof(gs));
     gs.phase = (E.games_budget > 0 && (long long)g >= E.games_budget) ? PH_HALT : PH_NEW_GAME;     // fewer games wanted than slots
     gs.pend_kind = PEND_NONE; gs.game_seq = (uint32_t)first_seq; gs.host_move = -1; gs.winner = RUNNING;
+    gs.slot_id = E.slot_offset + (uint32_t)g;
     E.trees[g * 2].root = -1; E.trees[g * 2 + 1].root = -1;
 }
 
@@ -74,9 +75,9 @@ template <class G> GAZ_KERNEL k_reset_games(DevParams<G> E, const int32_t* slots
     if (g < 0 || g >= E.n_games) return;
     GameState<G>& gs = E.games[g];
     const uint32_t seq = gs.game_seq + ((gs.phase == PH_NEW_GAME && gs.n_evals == 0) ? 0u : 1u);
-    const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies;
+    const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies; const uint32_t sid = gs.slot_id;
     memset(&gs, 0, sizeof(gs));
-    gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np;
+    gs.phase = PH_NEW_GAME; gs.game_seq = seq; gs.host_move = -1; gs.winner = RUNNING; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np; gs.slot_id = sid;
 }
 
 // put one slot at an arbitrary position (MCTS attaches to a live game object, MCTS.py:296-313): replay `n` actions on an empty
@@ -84,9 +85,9 @@ template <class G> GAZ_KERNEL k_reset_games(DevParams<G> E, const int32_t* slots
 template <class G> GAZ_KERNEL k_set_position(DevParams<G> E, int g, const int32_t* actions, int n) {
     if (block_id() != 0 || lane_id() != 0 || g < 0 || g >= E.n_games) return;
     GameState<G>& gs = E.games[g];
-    const uint32_t seq = gs.game_seq; const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies;
+    const uint32_t seq = gs.game_seq, sid = gs.slot_id; const uint64_t ne = gs.n_evals, ns = gs.n_sims, np = gs.n_plies;
     memset(&gs, 0, sizeof(gs));
-    gs.game_seq = seq; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np; gs.host_move = -1; gs.winner = RUNNING;
+    gs.game_seq = seq; gs.n_evals = ne; gs.n_sims = ns; gs.n_plies = np; gs.host_move = -1; gs.winner = RUNNING; gs.slot_id = sid;
     int player = -1;
     for (int i = 0; i < n && i < G::MAXT; ++i) {
         const int a = actions[i];
@@ -150,6 +151,39 @@ template <class G> GAZ_KERNEL k_probe_rules(DevParams<G> E, const int32_t* actio
     bool any_win;
     const int nt = terminal_probe<G>(S.board, S.legal, n_legal, player, S.tact, S.twin, any_win, E.fast_find_win != 0);
     for (int i = lane_id(); i < nt; i += WAVE) o_term[(size_t)p * G::A + S.tact[i]] = S.twin[i] ? 1 : 0;
+}
+
+// gaz_engine_repack: move the running game of physical slot `src` into the halted slot `dst` (dst < src).  Everything a game owns
+// travels: its tree arena slice, both tree heads, the path buffer, the record in progress, the Gumbel state, the rows of the
+// evaluator batch (a pending request's answer is waiting there) — and the GameState is SWAPPED, so the halted slot's lifetime
+// counters stay in the sum gaz_engine_get_stats reports.  The game keeps its identity (GameState::slot_id).
+template <class G> GAZ_KERNEL_WIDE k_move_slots(DevParams<G> E, const int32_t* moves, int n_moves, size_t arena_slot_bytes, size_t gstate_bytes) {
+#ifdef GAZ_HOST_EMU
+    const int b = block_id(), T = 1, t = 0;
+#else
+    const int b = blockIdx.x, T = blockDim.x, t = threadIdx.x;
+#endif
+    if (b >= n_moves) return;
+    const int src = moves[2 * b], dst = moves[2 * b + 1];
+    auto copy16 = [&](void* d, const void* s_, size_t bytes) {        // bytes % 16 == 0
+        uint4* dd = reinterpret_cast<uint4*>(d); const uint4* ss = reinterpret_cast<const uint4*>(s_);
+        for (size_t i = t; i < bytes / 16; i += T) dd[i] = ss[i];
+    };
+    auto copy1 = [&](void* d, const void* s_, size_t bytes) {
+        uint8_t* dd = reinterpret_cast<uint8_t*>(d); const uint8_t* ss = reinterpret_cast<const uint8_t*>(s_);
+        for (size_t i = t; i < bytes; i += T) dd[i] = ss[i];
+    };
+    copy16(E.arena + (size_t)dst * arena_slot_bytes, E.arena + (size_t)src * arena_slot_bytes, arena_slot_bytes);
+    copy16(E.recs + (size_t)dst * RecLayout<G>::SIZE, E.recs + (size_t)src * RecLayout<G>::SIZE, RecLayout<G>::SIZE);
+    copy1(E.paths + (size_t)dst * PathCap<G>::V, E.paths + (size_t)src * PathCap<G>::V, sizeof(PathEnt) * PathCap<G>::V);
+    copy1(&E.trees[(size_t)dst * 2], &E.trees[(size_t)src * 2], 2 * sizeof(TreeState));
+    if (E.gstate) copy1(reinterpret_cast<uint8_t*>(E.gstate) + (size_t)dst * gstate_bytes, reinterpret_cast<uint8_t*>(E.gstate) + (size_t)src * gstate_bytes, gstate_bytes);
+    copy1(E.nn_in + (size_t)dst * (G::HW * G::C), E.nn_in + (size_t)src * (G::HW * G::C), G::HW * G::C);
+    copy1(E.nn_policy + (size_t)dst * G::A, E.nn_policy + (size_t)src * G::A, 4 * G::A);
+    copy1(E.nn_value + dst, E.nn_value + src, 4);
+    // swap the two GameStates word by word (each thread its own words: no staging needed)
+    uint32_t* ga = reinterpret_cast<uint32_t*>(&E.games[src]); uint32_t* gb = reinterpret_cast<uint32_t*>(&E.games[dst]);
+    for (size_t i = t; i < sizeof(GameState<G>) / 4; i += T) { const uint32_t x = ga[i]; ga[i] = gb[i]; gb[i] = x; }
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
@@ -226,6 +260,7 @@ struct gaz_engine {
     virtual int set_hyperparams(const gaz_search_hyperparams*) = 0;
     virtual int read_head_features(int, float*, float*, int32_t*, int32_t*) = 0;
     virtual int set_fused_wave(int) = 0;
+    virtual int repack(int32_t*, int32_t*) = 0;
     virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
 
@@ -289,7 +324,7 @@ template <class G> struct EngineT : gaz_engine {
         E.node_bytes = gumbel ? gumbel_node_bytes<G>() : NodeLayout<G>::SIZE;
         // re-root compaction: needed where a whole-game arena does not fit (Gomoku: 4.2 KB records); 0 = auto
         E.compact = gumbel ? 0 : (cfg.compact_trees == 0 ? (G::ID == GAME_GMK ? 1 : 0) : (cfg.compact_trees > 0 ? 1 : 0));
-        E.n_games = n; E.run_iterations = cfg.run_iterations; E.max_actions = cfg.max_actions;
+        E.n_games = n; n_eff = n; E.run_iterations = cfg.run_iterations; E.max_actions = cfg.max_actions;
         if (cfg.max_actions > G::MAXT || cfg.max_actions <= 0) return fail("max_actions out of range for this game");
         E.explore_first = cfg.num_explore_actions_first; E.explore_second = cfg.num_explore_actions_second;
         E.create_new_root = cfg.create_new_root; E.sync_moves = cfg.sync_moves; E.use_dirichlet = cfg.use_dirichlet;
@@ -424,7 +459,7 @@ template <class G> struct EngineT : gaz_engine {
         if (PER > 1 && teams) GAZ_LAUNCH(k_wave_teams<GP>, (g1 - g0 + PER - 1) / PER, WAVE, st, *reinterpret_cast<const DevParams<GP>*>(&E), g0, g1);
         else GAZ_LAUNCH(k_wave<G>, g1 - g0, WAVE, st, E, g0, g1);
     }
-    void launch_wave() { launch_wave(stream, 0, E.n_games); }
+    void launch_wave() { launch_wave(stream, 0, n_eff); }
 
     // ---- fused tree + trunk launch (resnet.hip k_wave_trunk): Connect4 PUCT with the whole-trunk ResNet evaluator, no evaluation
     // cache (its probe reads rows other teams are writing).  GAZ_FUSE_WAVE=0 -> separate launches.
@@ -447,18 +482,63 @@ template <class G> struct EngineT : gaz_engine {
     bool fuse_enabled = true;
     int set_fused_wave(int on) override { fuse_enabled = on != 0; return 0; }
 
+    // ---- repack (continuous self-play with a games_budget): towards the end of a generation more and more slots have played their
+    // last game and halted, but every wave still steps and EVALUATES all n_games rows.  repack() moves the games that still run into
+    // the lowest slots and shrinks every later launch (tree step, evaluator, cache insert) to them: the tail of a generation costs
+    // what its live games cost.  Results do not change: a game carries its identity (slot_id) and all its state with it.
+    int n_eff = 0;                                   // launches cover physical slots [0, n_eff)
+    int32_t* dMoveList = nullptr;
+    int repack(int32_t* n_active_out, int32_t* n_eff_out) override {
+        if (E.sync_moves) return fail("repack needs continuous self-play (sync_moves = 0)");
+        HIP_OK(hipStreamSynchronize(stream));
+        if (pipeline_ready) { HIP_OK(hipStreamSynchronize(tstream)); HIP_OK(hipStreamSynchronize(hstream)); }
+        GAZ_LAUNCH(k_gather_root<G>, E.n_games, WAVE, stream, E, dN, dW, dP, dPol, dRV, dQ, dChosen, dPhase, dPending);
+        std::vector<int32_t> ph(E.n_games);
+        HIP_OK(hipMemcpyAsync(ph.data(), dPhase, (size_t)E.n_games * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        int n_active = 0;
+        for (int g = 0; g < n_eff; ++g) n_active += ph[g] != PH_HALT;
+        for (int g = n_eff; g < E.n_games; ++g) if (ph[g] != PH_HALT) return fail("repack: a slot beyond the live range is running");
+        if (n_active_out) *n_active_out = n_active;
+        const int n_new = n_active > 0 ? n_active : 1;
+        std::vector<int32_t> mv;
+        int hole = 0;
+        for (int g = n_eff - 1; g >= n_new; --g) {
+            if (ph[g] == PH_HALT) continue;
+            while (hole < n_new && ph[hole] != PH_HALT) ++hole;
+            if (hole >= n_new) return fail("repack: internal error (no hole left)");
+            mv.push_back(g); mv.push_back(hole); ph[hole] = ph[g]; ph[g] = PH_HALT;
+        }
+        if (!mv.empty()) {
+            if (!dMoveList && dalloc(&dMoveList, (size_t)2 * E.n_games)) return 1;
+            HIP_OK(hipMemcpyAsync(dMoveList, mv.data(), mv.size() * 4, hipMemcpyHostToDevice, stream));
+            const size_t slot_bytes = (size_t)2 * (E.compact ? 2 : 1) * (size_t)E.nodes_per_tree * (size_t)E.node_bytes;
+            const size_t gbytes = cfg.search == GAZ_SEARCH_GUMBEL ? sizeof(GumbelState<G>) : 0;
+#ifdef GAZ_HOST_EMU
+            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 1, stream, E, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
+#else
+            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 256, stream, E, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
+#endif
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(stream));
+        }
+        n_eff = n_new;
+        if (n_eff_out) *n_eff_out = n_eff;
+        return 0;
+    }
+
     int one_wave(bool with_eval) {
         if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
-            const void* plan = eval->trunk_plan(E.nn_in, E.n_games, 0, d_done, fuse_epoch + 1);
+            const void* plan = eval->trunk_plan(E.nn_in, n_eff, 0, d_done, fuse_epoch + 1);
             if (plan) {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
                 if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
                 DevParams<G> Ef = E; Ef.done_flag = d_done; Ef.wave_epoch = ++fuse_epoch;
-                launch_wave_trunk_c4(stream, &Ef, 0, E.n_games, plan);
+                launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
                 if (timing) hipEventRecord(e1, stream);
-                eval->forward_heads(stream, E.nn_policy, E.nn_value, E.n_games, 0);
-                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
+                eval->forward_heads(stream, E.nn_policy, E.nn_value, n_eff, 0);
+                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, E, 0, n_eff); E.cache_epoch++; }
                 if (timing) {       // the fused kernel is booked as evaluator time; tree time is what it hides
                     hipEventRecord(e2, stream); ev_eval.push_back({e0, e2}); n_waves_timed++;
                     ev_fused.push_back({e0, e1});
@@ -474,9 +554,9 @@ template <class G> struct EngineT : gaz_engine {
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
         launch_wave();
         if (timing) hipEventRecord(e1, stream);
-        if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, E.n_games, timing);
+        if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, n_eff, timing);
         if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); n_waves_timed++; }
-        if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, E.n_games, WAVE, stream, E, 0, E.n_games); E.cache_epoch++; }
+        if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, E, 0, n_eff); E.cache_epoch++; }
         n_waves_total++;
         return 0;
     }
@@ -496,7 +576,7 @@ template <class G> struct EngineT : gaz_engine {
         static const char* spec = getenv("GAZ_PIPELINE");
         if (!spec || !*spec || atoi(spec) == 0) return false;
         // (the evaluation cache is read by tree kernels and written by k_cache_insert: they must not run concurrently)
-        if (E.sync_moves || !eval || !eval->supports_split() || E.n_games < 1024 || E.cache) return false;
+        if (E.sync_moves || !eval || !eval->supports_split() || E.n_games < 1024 || E.cache || n_eff != E.n_games) return false;
         if (!pipeline_ready) {
             // GAZ_PIPELINE=1: groups of one full trunk round (1536 boards), remainder last; GAZ_PIPELINE=a,b,c: explicit sizes
             std::vector<int> sizes;
@@ -881,6 +961,7 @@ int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
 int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on) { return h->set_fused_wave(on); }
+int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch) { return h->repack(n_active, n_launch); }
 int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p, float* v, int32_t* p_row, int32_t* v_row) { return h->read_head_features(n, p, v, p_row, v_row); }
 int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,
                            uint8_t* legal, int32_t* winner, int8_t* input, int32_t* terminal, const float* policy_in, float* policy_out) {

@@ -646,7 +646,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             if (ended && tlane<G>() == 0) {
                 gs.winner = winner;
                 int32_t* hdr = reinterpret_cast<int32_t*>(rec);
-                hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)(E.slot_offset + (uint32_t)g); hdr[3] = (int32_t)gs.game_seq;
+                hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)gs.slot_id; hdr[3] = (int32_t)gs.game_seq;
                 atomic_max(&E.stats[0], (unsigned long long)(ply + 1));
                 atomic_add(&E.stats[1], (unsigned long long)(ply + 1));
                 atomic_add(&E.stats[2], 1ull);

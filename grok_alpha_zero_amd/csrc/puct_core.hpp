@@ -133,7 +133,7 @@ GAZ_DEV void set_error(int32_t* err, int32_t code) {      // any lane of any tea
 template <class G> GAZ_DEV det::Event make_event(const DevParams<G>& E, int g, const GameState<G>& gs, TreeState& ts,
                                                  int tree, uint32_t purpose) {
     det::Event e;
-    e.key0 = E.key0; e.key1 = E.key1; e.slot = E.slot_offset + (uint32_t)g; e.game_seq = gs.game_seq;
+    e.key0 = E.key0; e.key1 = E.key1; e.slot = gs.slot_id; e.game_seq = gs.game_seq;
     e.event = ts.event; e.tree = (uint32_t)tree; e.purpose = purpose;
     return e;
 }
@@ -793,7 +793,7 @@ template <class G> GAZ_DEV int opening_override(const DevParams<G>& E, int g, co
     int acts[9]; double w[9]; int n = E.n_opening; double sum = 0.0;
     for (int i = 0; i < n; ++i) { acts[i] = E.opening_actions[i]; w[i] = E.opening_weights[i]; sum = sum + w[i]; }
     if (sum < 1.0) { acts[n] = mcts_action; w[n] = 1.0 - sum; n++; }
-    det::Event e; e.key0 = E.key0; e.key1 = E.key1; e.slot = E.slot_offset + (uint32_t)g; e.game_seq = gs.game_seq;
+    det::Event e; e.key0 = E.key0; e.key1 = E.key1; e.slot = gs.slot_id; e.game_seq = gs.game_seq;
     e.event = 0; e.tree = 2; e.purpose = det::P_OPENING;
     const double u = det::uniform(e);
     double cdf[9], acc = 0.0;
@@ -825,7 +825,7 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
             gs.game_seq += 1;
             // a generation = the first games_budget games STARTED, each run to its end (Self_Play.py:346-408): stop restarting
             const long long k = (long long)(gs.game_seq - E.first_game_seq);
-            gs.phase = (E.games_budget > 0 && k * (long long)E.n_games + (long long)g >= E.games_budget) ? PH_HALT : PH_NEW_GAME;
+            gs.phase = (E.games_budget > 0 && k * (long long)E.n_games + (long long)(gs.slot_id - E.slot_offset) >= E.games_budget) ? PH_HALT : PH_NEW_GAME;
         }
     }
     wave_sync();
@@ -1024,7 +1024,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                 if (tlane<G>() == 0) {
                     gs.winner = winner;
                     int32_t* hdr = reinterpret_cast<int32_t*>(rec);
-                    hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)(E.slot_offset + (uint32_t)g); hdr[3] = (int32_t)gs.game_seq;
+                    hdr[0] = ply + 1; hdr[1] = winner; hdr[2] = (int32_t)gs.slot_id; hdr[3] = (int32_t)gs.game_seq;
                     atomic_max(&E.stats[0], (unsigned long long)(ply + 1));            // game_stats (Self_Play.py:181-188)
                     atomic_add(&E.stats[1], (unsigned long long)(ply + 1));
                     atomic_add(&E.stats[2], 1ull);

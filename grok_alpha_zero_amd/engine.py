@@ -94,6 +94,7 @@ def load_library(lib_path=None):
     L.gaz_engine_set_hyperparams.argtypes = [H, C.POINTER(SearchHyperparams)]
     L.gaz_engine_probe_rules.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.gaz_engine_set_fused_wave.argtypes = [H, C.c_int32]
+    L.gaz_engine_repack.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_read_head_features.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
     L.gaz_engine_timing_get.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -101,7 +102,7 @@ def load_library(lib_path=None):
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
               "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search",
-              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave"):
+              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave", "repack"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -333,6 +334,12 @@ class SelfPlayEngine:
                     evals=arr(lay.off_evals, np.uint32, (lay.max_T,))[:T])
 
     # ---- measurement ----------------------------------------------------------------------------------
+    def repack(self):
+        """Move the games still running to the lowest slots and shrink the launches to them (generation tails); -> (active, launch size)."""
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.L.gaz_engine_repack(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_fused_wave(self, on=True):
         """tree step + trunk kernel as one launch (default where available) or as separate launches; results do not change"""
         self._ck(self.L.gaz_engine_set_fused_wave(self.h, int(bool(on))))

@@ -356,12 +356,18 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     if use_net:
         eng.load_weights(weights)
     written = 0
+    launch = G                                          # slots the launches cover (shrinks in the generation's tail, see repack)
     try:
         with store.writing():
             eng.run_waves(64)
             idle = 0
             while written < games_left:
                 recs = eng.drain_finished()             # waits for the launches queued so far
+                # tail of the generation: every game has been started and the slots halt one by one, but a wave still evaluates all
+                # of them — once half of the covered slots are idle, move the live games together and shrink the launches
+                remaining = games_left - written - len(recs)          # games not finished yet >= games still running
+                if 0 < remaining and remaining * 2 <= launch and launch > 16:
+                    _, launch = eng.repack()
                 eng.run_waves(64)                       # queue the next ones right away: the GPU works while the host converts and writes
                 for rec in recs:                        # every record is one of the admitted games (games_budget)
                     aug_b, aug_p, aug_v, length = record_to_samples(game_class, rec)

@@ -26,6 +26,7 @@
  *                                 MCTS_Gumbel.update_hyperparams(m, c_visit, c_scale)  MCTS_Gumbel.py:186-210
  *   gaz_engine_probe_rules     the Game plugin's static *_MCTS functions          Guide.py:135-283, Game_Tester.py:297-405
  *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
+ *   gaz_engine_repack             finished workers no longer load the inference server  Self_Play.py:380-400
  *   gaz_engine_set_fused_wave     (scheduling switch; no reference counterpart: Client_Server.py's server loop is what it replaces)
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  *   gaz_engine_read_head_features  intermediate tensors of that probe (numerics tests)  Connect4/Build_Model.py:41-47,62-66
@@ -196,6 +197,13 @@ int gaz_engine_synchronize(gaz_engine* h);
  * starts on the boards whose games are done while the slow games still search); on = 0 launches them separately (same results bit
  * for bit; bench.py uses it to time the trunk kernel on its own).  Scheduling only. */
 int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on);
+
+/* Continuous self-play with a games_budget: towards the end of a generation more and more slots have played their last game, but a
+ * wave still steps and evaluates every slot.  repack moves the games that still run into the lowest slots (tree arena slice, records,
+ * pending evaluator rows; a game keeps its identity) and shrinks all later launches to them.  *n_active = games still running,
+ * *n_launch = slots the launches cover from now on.  Results do not change.  (The reference's counterpart is simply that finished
+ * worker processes stop asking the inference server, Self_Play.py:380-400.) */
+int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);

@@ -200,3 +200,46 @@ def test_evaluation_cache_changes_nothing_but_the_wave_count(game, search, iters
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(ra[k][f]), np.asarray(rb[k][f]), err_msg=f"{k} {f}")
     eng_a.close(); eng_b.close()
+
+
+def _repack_run(lib_path, oracle, game, G, budget, iters, max_actions, search_kw, oracle_fn):
+    """continuous self-play with a games_budget; whenever half of the covered slots have halted the live games are moved together
+    (gaz_engine_repack) — every admitted game must still come out equal to the oracle's"""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine
+    eng = SelfPlayEngine(game, G, iters, max_actions, 4, 3, 2.5, 0.5, seed=13, hash_salt=6, slot_offset=200, ring_capacity=4 * G,
+                         games_budget=budget, lib_path=lib_path, **search_kw)
+    recs, launch, repacks = [], G, 0
+    for _ in range(100000):
+        eng.run_waves(16)
+        recs += eng.drain_finished()
+        remaining = budget - len(recs)
+        if remaining == 0:
+            break
+        if remaining * 2 <= launch and launch > 2:
+            active, launch = eng.repack()
+            assert active <= remaining and launch == max(active, 1)
+            repacks += 1
+    assert len(recs) == budget and repacks >= 2
+    st = eng.stats()
+    assert st["game_stats"][2] == budget and st["plies"] == sum(r["T"] for r in recs)      # lifetime counters survive the moves
+    eng.close()
+    keys = {(r["slot"], r["game_seq"]) for r in recs}
+    assert keys == {(200 + g, k) for k in range(8) for g in range(G) if k * G + g < budget}
+    for r in recs:
+        o = oracle_fn(r["slot"], r["game_seq"])
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']} seq {r['game_seq']}")
+
+
+def test_emu_repack_keeps_every_game(emu_lib, oracle):
+    _repack_run(emu_lib, oracle, "Connect4", 24, 60, 20, 42, {},
+                lambda s, q: oracle.selfplay_game("Connect4", 20, 42, 4, 3, 2.5, 0.5, 13, s, q, hash_salt=6))
+
+
+def test_emu_repack_keeps_every_game_gumbel_and_compaction(emu_lib, oracle):
+    from grok_alpha_zero_amd.engine import SEARCH_GUMBEL
+    _repack_run(emu_lib, oracle, "Connect4", 12, 30, 16, 42, dict(search=SEARCH_GUMBEL, gumbel_m=4, c_visit=50.0, c_scale=1.0),
+                lambda s, q: oracle.selfplay_game_gumbel("Connect4", 16, 42, 4, 50.0, 1.0, 13, s, q, hash_salt=6))
+    _repack_run(emu_lib, oracle, "Connect4", 10, 24, 16, 42, dict(compact_trees=1),
+                lambda s, q: oracle.selfplay_game("Connect4", 16, 42, 4, 3, 2.5, 0.5, 13, s, q, hash_salt=6))

@@ -363,3 +363,46 @@ def test_hip_evaluation_cache_gives_identical_games(G, ring):
     for k in common:
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(ra[k][f]), np.asarray(rb[k][f]), err_msg=f"{k} {f}")
+
+
+def test_hip_repack_keeps_every_game(oracle):
+    """gaz_engine_repack on the GPU (tail of a generation: the live games are moved to the lowest slots, launches shrink to them):
+    every admitted game of a 1300-game generation on 512 slots still equals the oracle's."""
+    from test_engine_emu import _repack_run
+    ora = {}
+
+    def fn(s, q):
+        return oracle.selfplay_game("Connect4", 30, 42, 4, 3, 2.5, 0.5, 13, s, q, hash_salt=6)
+    _repack_run(None, oracle, "Connect4", 512, 1300, 30, 42, {}, fn)
+
+
+def test_hip_repack_with_network_fused_launch_and_cache():
+    """The same with everything on that run_self_play uses: ResNet evaluator, fused tree + trunk launch, evaluation cache.  A run that
+    repacks whenever half of its slots idle must produce the very records of a run that never does."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=8).eval().export_engine_weights()
+    G, budget = 768, 1800
+    out = []
+    for do_repack in (True, False):
+        eng = SelfPlayEngine("Connect4", G, 24, 42, 4, 3, 2.5, 0.5, seed=3, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=4 * G,
+                             eval_cache_log2=16, games_budget=budget)
+        eng.load_weights(w)
+        recs, launch, n_repack = [], G, 0
+        for _ in range(4000):
+            eng.run_waves(32)
+            recs += eng.drain_finished()
+            remaining = budget - len(recs)
+            if remaining == 0:
+                break
+            if do_repack and remaining * 2 <= launch and launch > 16:
+                _, launch = eng.repack(); n_repack += 1
+        assert len(recs) == budget and (n_repack >= 3) == do_repack
+        assert eng.stats()["fused_wave"] == 1
+        eng.close()
+        out.append({(r["slot"], r["game_seq"]): r for r in recs})
+    a, b = out
+    assert set(a) == set(b)
+    for k in a:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
