@@ -310,29 +310,13 @@ __global__ __launch_bounds__(128) void k_dense1(const float* feat, const float* 
 struct Dense1Args { const float* feat[2]; const float* w[2]; const float* scale[2]; const float* shift[2]; float* out[2]; int B, F; };
 __global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
     extern __shared__ float fl[];                  // [32][FP], FP = F rounded up to 16, + 1 (zero-padded columns)
-    constexpr int G = 8, D = 4;                    // 16 k per group, four-deep register ring of weight groups
+    constexpr int G = 8, D = 6;                    // 16 k per group, six-deep register ring of weight groups
     const int head = blockIdx.y, b0 = blockIdx.x * 32, F = a.F, NG = (F + 2 * G - 1) / (2 * G), FP = NG * 2 * G + 1;
     const float* feat = a.feat[head]; const float* w = a.w[head];
-    // one wave per position row, coalesced; loads are unconditional (clamped) and issued six at a time — a plain
-    // load -> store loop costs one L2 round trip per iteration
-    for (int p = threadIdx.x >> 6; p < 32; p += 4) {
-        const size_t rb = (size_t)min(b0 + p, a.B - 1) * F;
-        const bool rok = b0 + p < a.B;
-        for (int kb = threadIdx.x & 63; kb < FP; kb += 64 * 6) {
-            float v[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v[c] = feat[rb + min(kb + 64 * c, F - 1)];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { const int k = kb + 64 * c; if (k < FP) fl[p * FP + k] = (rok && k < F) ? v[c] : 0.0f; }
-        }
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, n = wave * 32 + l31;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // A[i = l31][k + lhi], B[k + lhi][j = l31].  The weights come from L2 (~1 us away under load): the next three groups
-    // are in flight while a group multiplies.  Loads past the last row are clamped (their A columns are zero).
+    // A[i = l31][k + lhi], B[k + lhi][j = l31].  The weights come from L2 (~1 us away under load): the next five groups are in
+    // flight while a group multiplies, and the first five are requested BEFORE the features are staged (round 2: the kernel is a chain
+    // of round trips with one wave per SIMD, nothing else hides them).  Loads past the last row are clamped (their A columns are zero).
     float bq[D][G];
     auto ldg = [&](int g, float* dst) {
 #pragma unroll
@@ -340,6 +324,31 @@ __global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
     };
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) ldg(d, bq[d]);
+    // features -> LDS: one wave per position row, coalesced; loads are unconditional (clamped).  ALL of a wave's loads (8 rows x 6) are
+    // issued before its first LDS store: one round trip for the staging instead of one per row.
+    {
+        float v[8][6];
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) {
+            const int p = wave + 4 * pi;
+            const size_t rb = (size_t)min(b0 + p, a.B - 1) * F;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[pi][c] = feat[rb + min(lane + 64 * c, F - 1)];
+        }
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) {
+            const int p = wave + 4 * pi;
+            const bool rok = b0 + p < a.B;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { const int k = lane + 64 * c; if (k < FP) fl[p * FP + k] = (rok && k < F) ? v[pi][c] : 0.0f; }
+        }
+        for (int p = wave; p < 32; p += 4)           // F > 384 (not the Connect4 net): the rest of the row, the old way
+            for (int k = lane + 64 * 6; k < FP; k += 64) fl[p * FP + k] = (b0 + p < a.B && k < F) ? feat[(size_t)min(b0 + p, a.B - 1) * F + k] : 0.0f;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     for (int g0 = 0; g0 < NG; g0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
