@@ -601,7 +601,8 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_conv_heads(HeadsConvArgs a) 
 // register ring; the image is reloaded by LDS-DMA between the phases (5 loads instead of 1, the price of not writing
 // h = conv1(...) and proj(x0) to HBM and back: 873 us for three kernels before).
 struct Block0Args {
-    const bf16_t* a0; const bf16_t* x0;           // [M][256] pre-activated / raw stem output
+    const bf16_t* a0; const bf16_t* x0;           // [M][256] pre-activated / raw stem output.  a0 == null (round 2): the stem writes only x0 and
+    const float* s1; const float* t1;             // conv1's operand relu(x0 * s1 + t1) is made IN LDS after the image landed ([256] each)
     bf16_t* xout;                                 // [M][128]
     const bf16_t* w;                              // 29 slices [8 k-steps][2][128 cout][8] (fragment order)
     const float* s2; const float* t2;             // bn2 folded with conv1's bias (ReLU)
@@ -632,7 +633,27 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_block0(Block0Args a) {
             __builtin_amdgcn_global_load_lds((const void*)(in4 + gr * (2 * SLOTS) + half * SLOTS + (sp ^ (lr & 15))), (lds_ptr_t)(As + base), 16, 0, 0);
         }
     };
-    load_image(a.a0, 0, m0 - 2 * h, ROWS + 2 * h);
+    // in-place pre-activation of the image just loaded from the RAW stem output: slot i of image row lr holds channels
+    // 128 half + 8 (sp ^ (lr & 15)) ..+7 (the swizzle went through the DMA's source address)
+    auto preactivate = [&](int half, int nrows) {
+        for (int i = tid; i < nrows * SLOTS; i += RB3_THREADS) {
+            const int lr = i / SLOTS, sp = i % SLOTS, c0 = half * 128 + ((sp ^ (lr & 15)) << 3);
+            const float4 sa = *reinterpret_cast<const float4*>(a.s1 + c0), sb = *reinterpret_cast<const float4*>(a.s1 + c0 + 4);
+            const float4 ta = *reinterpret_cast<const float4*>(a.t1 + c0), tb = *reinterpret_cast<const float4*>(a.t1 + c0 + 4);
+            const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w}, sh[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+            const uint4 v = As[i];
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = fmaxf(__uint_as_float(w[j] << 16) * sc[2 * j] + sh[2 * j], 0.0f);
+                const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * sc[2 * j + 1] + sh[2 * j + 1], 0.0f);
+                w[j] = pack_bf16(lo, hi);
+            }
+            As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    const bool inplace = a.a0 == nullptr;
+    load_image(inplace ? a.x0 : a.a0, 0, m0 - 2 * h, ROWS + 2 * h);
     if (tid < SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
 
     typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -725,11 +746,13 @@ __global__ __launch_bounds__(RB3_THREADS, 2) void k_block0(Block0Args a) {
     };
 
     zero_acc();
-    __syncthreads();                                // a0 low half landed
+    __syncthreads();                                // a0 / x0 low half landed
+    if (inplace) { preactivate(0, ROWS + 2 * h); __syncthreads(); }
     run_slices(0, 9, true, 0);                      // conv1, input channels 0-127
     __syncthreads();                                // every wave is done with this image
-    load_image(a.a0, 1, m0 - 2 * h, ROWS + 2 * h);
+    load_image(inplace ? a.x0 : a.a0, 1, m0 - 2 * h, ROWS + 2 * h);
     __syncthreads();
+    if (inplace) { preactivate(1, ROWS + 2 * h); __syncthreads(); }
     run_slices(9, 9, true, 0);                      // conv1, input channels 128-255
     __syncthreads();
     {   // h = relu(acc * s2 + t2) as bf16 into the image region (row j of h at image row j, same swizzle)
