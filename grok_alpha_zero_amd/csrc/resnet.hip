@@ -238,19 +238,8 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DenseMArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     for (int k0 = 0; k0 < K; k0 += DM_KC) {
         const int kc = K - k0 < DM_KC ? K - k0 : DM_KC, NG = (kc + 2 * G - 1) / (2 * G);
-        __syncthreads();                           // the previous chunk's readers are done
-        for (int p = threadIdx.x >> 6; p < 32; p += 4) {
-            const size_t rb = (size_t)min(b0 + p, a.B - 1) * K + k0;
-            const bool rok = b0 + p < a.B;
-            for (int kb = threadIdx.x & 63; kb < NG * 2 * G; kb += 64 * 7) {
-                float v[7];
-#pragma unroll
-                for (int c = 0; c < 7; ++c) v[c] = a.in[rb + min(kb + 64 * c, kc - 1)];
-#pragma unroll
-                for (int c = 0; c < 7; ++c) { const int k = kb + 64 * c; if (k < NG * 2 * G) fl[p * FP + k] = (rok && k < kc) ? v[c] : 0.0f; }
-            }
-        }
-        __syncthreads();
+        // round 2: the chunk's first weight groups and ALL of a wave's staging loads (8 rows x 7) are in flight before the first LDS
+        // store — the old per-row load -> store loop cost one L2 round trip per row and chunk (40 in a row for K = 1800)
         float bq[D][G];
         auto ldg = [&](int g, float* dst) {
 #pragma unroll
@@ -258,6 +247,25 @@ __global__ __launch_bounds__(256) void k_dense_mfma(DenseMArgs a) {
         };
 #pragma unroll
         for (int d = 0; d < D - 1; ++d) ldg(d, bq[d]);
+        {
+            float v[8][7];
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+            for (int pi = 0; pi < 8; ++pi) {
+                const size_t rb = (size_t)min(b0 + wv + 4 * pi, a.B - 1) * K + k0;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) v[pi][c] = a.in[rb + min(ln + 64 * c, kc - 1)];
+            }
+            __syncthreads();                       // the previous chunk's readers are done
+#pragma unroll
+            for (int pi = 0; pi < 8; ++pi) {
+                const int p = wv + 4 * pi;
+                const bool rok = b0 + p < a.B;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) { const int k = ln + 64 * c; if (k < NG * 2 * G) fl[p * FP + k] = (rok && k < kc) ? v[pi][c] : 0.0f; }
+            }
+        }
+        __syncthreads();
         for (int g0 = 0; g0 < NG; g0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
