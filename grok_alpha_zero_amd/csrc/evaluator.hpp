@@ -28,7 +28,6 @@ struct Evaluator {
     // fused tree + trunk launch (fused.hip): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
     // planes of board b are valid once ready[b] == epoch.  Null = this evaluator / configuration cannot be fused.
     virtual const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) { (void)in; (void)n; (void)p0; (void)ready; (void)epoch; return nullptr; }
-    virtual void note_fused_launch(hipEvent_t e0, hipEvent_t e1) { (void)e0; (void)e1; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }

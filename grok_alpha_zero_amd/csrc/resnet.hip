@@ -594,7 +594,6 @@ struct ResNetEvaluator : Evaluator {
         fused_plan.args.ready = ready; fused_plan.args.epoch = epoch;
         return &fused_plan;
     }
-    void note_fused_launch(hipEvent_t e0, hipEvent_t e1) override { tev.push_back(e0); tev.push_back(e1); }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         forward_trunk(s, in, n, timing, p0);
