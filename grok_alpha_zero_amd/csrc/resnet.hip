@@ -886,6 +886,7 @@ struct GenericEvaluator : Evaluator {
         hipLaunchKernelGGL(k_dense, dim3((n + 7) / 8), dim3(128), (size_t)8 * K * 4, s, in, f32[w], sc, sh, out, n, K, N, act);
     }
     float* g(const std::string& k) { return f32[k]; }
+    bool head_features(const float** p, const float** v, int* pr, int* vr) override { *p = pfeat; *v = vfeat; *pr = HW * 8; *vr = HW * 4; return true; }
 
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int = 0) override {
         if (!loaded) return;

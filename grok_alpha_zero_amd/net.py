@@ -290,6 +290,52 @@ class GomokuNet(nn.Module):
         return p, v
 
     @torch.no_grad()
+    def forward_engine_numerics(self, x):
+        """The Gomoku network as the HIP kernels compute it (bf16 roundings where they round, fp32 elsewhere, convolutions summed in
+        float64) — see Connect4Net.forward_engine_numerics.  Rounding points: stem output x0 (k_stem_mfma, hi + lo weight split, ReLU);
+        block 0 (k_block0): a0 = bf16(relu(x0 s1 + t1)) made in LDS, h = bf16(relu(conv1 s2 + t2')), x = bf16(conv2(h) + proj(x0) +
+        (b2 + bp)) with conv2 and the 1x1 projection in ONE accumulator; blocks 1.. (k_trunk) as Connect4; heads (k_conv_head32):
+        a = bf16(relu(x s0 + t0)), c1 = bf16(relu(conv s1 + t1')); then fp32: second head conv (k_conv_small) + flat BN + ReLU, Dense
+        layers, softmax / tanh."""
+        bf = lambda t: t.float().to(torch.bfloat16).float()
+        B = x.shape[0]
+
+        def conv(a, w, pad):
+            y = F.conv2d(a.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=pad)
+            return y.permute(0, 2, 3, 1)                 # float64: the caller rounds where the kernel does
+        s, t = self.stem_bn.affine()
+        wv = (self.stem.weight * s).float()
+        hi = bf(wv); lo = bf(wv - hi)
+        xs = bf(F.relu(conv(x.float(), hi.double() + lo.double(), 1).float() + (self.stem.bias * s + t)))
+        for b in self.blocks:
+            s1, t1 = b.bn1.affine(); s2, t2 = b.bn2.affine()
+            a = bf(F.relu(xs * s1 + t1))
+            h = bf(F.relu(conv(a, bf(b.conv1.weight), 1).float() * s2 + (b.conv1.bias * s2 + t2)))
+            if b.proj is not None:                       # conv2 and the projection accumulate together; one fp32 bias (b2 + bp)
+                acc = (conv(h, bf(b.conv2.weight), 1) + conv(xs, bf(b.proj.weight), 0)).float()
+                xs = bf(acc + (b.conv2.bias + b.proj.bias))
+            else:
+                xs = bf((conv(h, bf(b.conv2.weight), 1).float() + b.conv2.bias) + xs)
+        out = {}
+        s0, t0 = self.p_bn0.affine(); s1, t1 = self.p_bn1.affine(); s2, t2 = self.p_bn2.affine()
+        c1 = bf(F.relu(conv(bf(F.relu(xs * s0 + t0)), bf(self.p_c1.weight), 1).float() * s1 + (self.p_c1.bias * s1 + t1)))
+        pf = F.relu((conv(c1, self.p_c2.weight, 1).float() + self.p_c2.bias).reshape(B, -1) * s2 + t2)
+        s3, t3 = self.p_bn3.affine()
+        y = F.relu((pf.double() @ self.p_d1.weight.double()).float() * s3 + (self.p_d1.bias * s3 + t3))
+        logits = (y.double() @ self.p_d2.weight.double() + self.p_d2.bias.double()).float()
+        s0, t0 = self.v_bn0.affine(); s1, t1 = self.v_bn1.affine(); s2, t2 = self.v_bn2.affine()
+        c1 = bf(F.relu(conv(bf(F.relu(xs * s0 + t0)), bf(self.v_c1.weight), 1).float() * s1 + (self.v_c1.bias * s1 + t1)))
+        vf = F.relu((conv(c1, self.v_c2.weight, 0).float() + self.v_c2.bias).reshape(B, -1) * s2 + t2)
+        s3, t3 = self.v_bn3.affine(); s4, t4 = self.v_bn4.affine()
+        y = F.relu((vf.double() @ self.v_d1.weight.double()).float() * s3 + (self.v_d1.bias * s3 + t3))
+        y = F.relu((y.double() @ self.v_d2.weight.double()).float() * s4 + (self.v_d2.bias * s4 + t4))
+        vpre = (y.double() @ self.v_d3.weight.double() + self.v_d3.bias.double()).float().reshape(-1)
+        out["p_feat"] = pf; out["v_feat"] = vf; out["logits"] = logits; out["v_pre"] = vpre
+        out["policy"] = torch.softmax(logits, -1) if self.policy_head == "softmax" else (stablemax(logits) if self.policy_head == "stablemax" else logits)
+        out["value"] = torch.tanh(vpre)
+        return {k: v.numpy() for k, v in out.items()}
+
+    @torch.no_grad()
     def export_engine_weights(self):
         o = {}
         s, t = self.stem_bn.affine()

@@ -364,3 +364,55 @@ def test_fused_tree_and_trunk_launch_gives_identical_games():
     for k in a:
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
+
+
+@pytest.mark.parametrize("blocks,active,n", [(2, 1, 23), (2, -1, 9), (10, 1, 12), (10, 5, 12), (10, 9, 33)])
+def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n):
+    """The Gomoku network's kernels (k_stem_mfma, k_block0 with its in-LDS pre-activation and the projection accumulated into conv2,
+    the 8-wave k_trunk for blocks 1.., k_conv_head32, k_conv_small, the fp32 dense chain) against GomokuNet.forward_engine_numerics —
+    the same network with a bf16 rounding at exactly the points these kernels round.  Block 0 (it carries the 256 -> 128 projection)
+    is always live; of blocks 1.. ONE is active at a time (the others have zero convolution weights and conv2 bias and pass the
+    residual stream through bit for bit), so every slice of the 10-block weight stream is checked with only a few rounding stages
+    between input and output (block 0's two, the active block's two, the heads' bf16 conv output).  Measured on the MI355X: block 0
+    alone — feature mean 7e-5, logits 3.8e-3, probabilities 1e-4; block 0 + one more — feature mean 6 - 12e-4 (isolated elements up to
+    3.8e-2 of max(|f|, 1): flipped bf16 roundings two stages up), logits 2.2e-2, probabilities 2.3e-3.  Asserted with ~2x margin; a wrong
+    tap at a board edge or a swapped channel group shows as O(1) feature errors, 20x above these bounds (the fp32 comparison above
+    allows 0.15 on probabilities).  active = -1: block 0 alone is live (both convolutions of block 1 zeroed)."""
+    import torch
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import GomokuNet
+    rng = np.random.default_rng(blocks * 100 + n)
+    x = rng.integers(-1, 2, size=(n, 15, 15, 2)).astype(np.int8)
+    x[..., 0] = rng.choice([-1, 1], size=(n, 1, 1))
+    m = {}
+    for head, logits_mode in (("linear", 1), ("softmax", 0)):
+        net = GomokuNet(blocks, seed=21, policy_head=head).eval().randomize_bn(5)
+        with torch.no_grad():
+            for i, b in enumerate(net.blocks):
+                if i >= 1 and i != active:
+                    b.conv1.weight.zero_(); b.conv2.weight.zero_(); b.conv2.bias.zero_()
+        eng = SelfPlayEngine("Gomoku", max(n, 8), 50, 150, 2, 1, 1.25, 1.0, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks, net_filters=128,
+                             ring_capacity=0, policy_is_logits=logits_mode)
+        eng.load_weights(net.export_engine_weights())
+        pol, val, _ = eng.evaluate(x)
+        pf, vf = eng.head_features(n)
+        eng.close()
+        ref = net.forward_engine_numerics(torch.from_numpy(x))
+        assert np.isfinite(pol).all() and np.isfinite(val).all()
+        for name, got, want in (("p_feat", pf, ref["p_feat"]), ("v_feat", vf, ref["v_feat"])):
+            d = np.abs(got - want)
+            m[name + "_rel_max"] = float((d / np.maximum(np.abs(want), 1.0)).max()); m[name + "_mean"] = float(d.mean())
+        m["value_max"] = float(np.abs(val - ref["value"]).max())
+        ok = np.abs(ref["v_pre"]) < 2.5
+        m["vpre_max"] = float(np.abs(np.arctanh(np.clip(val[ok].astype(np.float64), -0.999999, 0.999999)) - ref["v_pre"][ok]).max()) if ok.any() else 0.0
+        if logits_mode:
+            m["logits_max"] = float(np.abs(pol - ref["logits"]).max())
+        else:
+            m["prob_max"] = float(np.abs(pol - ref["policy"]).max())
+    print("gomoku faithful metrics", blocks, active, m)
+    if active < 0:
+        assert m["p_feat_rel_max"] <= 4e-2 and m["v_feat_rel_max"] <= 4e-2 and m["p_feat_mean"] <= 2e-4 and m["v_feat_mean"] <= 2e-4, m
+        assert m["logits_max"] <= 8e-3 and m["vpre_max"] <= 8e-3 and m["prob_max"] <= 5e-4 and m["value_max"] <= 2e-3, m
+    else:
+        assert m["p_feat_rel_max"] <= 8e-2 and m["v_feat_rel_max"] <= 8e-2 and m["p_feat_mean"] <= 2.5e-3 and m["v_feat_mean"] <= 2.5e-3, m
+        assert m["logits_max"] <= 4e-2 and m["vpre_max"] <= 3e-2 and m["prob_max"] <= 5e-3 and m["value_max"] <= 1e-2, m
