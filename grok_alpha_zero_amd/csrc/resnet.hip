@@ -745,11 +745,15 @@ struct GenericEvaluator : Evaluator {
     bf16_t *X0 = nullptr, *A0 = nullptr, *X = nullptr, *Aa = nullptr, *Hh = nullptr, *Va = nullptr, *PH = nullptr, *VH = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
     std::vector<hipEvent_t> tev; int trunk_convs = 0;
-    bool fused = true, block0_fused = false, block0_inplace = false; int n_cus = 256, fused_blocks = 0;   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
+    bool fused = true, block0_fused = false, block0_inplace = false; int n_cus = 256, fused_blocks = 0;
+    hipStream_t side_stream = 0; hipEvent_t ev_fork = 0, ev_join = 0;     // value head next to the policy head (Gomoku)   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
     bool trunk = true, trunk_m16 = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
     bf16_t* stem_frag = nullptr;
 
-    ~GenericEvaluator() override { for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e); }
+    ~GenericEvaluator() override {
+        if (side_stream) { hipStreamSynchronize(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); hipStreamDestroy(side_stream); }
+        for (void* p : allocs) hipFree(p); for (auto e : tev) hipEventDestroy(e);
+    }
     template <class T> T* dalloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n + 64) * sizeof(T)) != hipSuccess) return nullptr; allocs.push_back(p); return (T*)p; }
     bool ready() const override { return loaded; }
 
@@ -987,18 +991,28 @@ struct GenericEvaluator : Evaluator {
                 conv_mfma32(s, Aa, b16["p.c1.w"], g("p.c1.scale"), g("p.c1.shift"), PH, M);
                 conv_mfma32(s, Va, b16["v.c1.w"], g("v.c1.scale"), g("v.c1.shift"), VH, M);
             }
+            // the two heads are independent chains of small kernels (policy ~0.22 ms, value ~0.08 ms per 2048 positions): the value head
+            // runs on a side stream next to the policy head and joins before the softmax (round 2; GAZ_HEADS_2STREAMS=0 -> one stream)
+            static const bool two = !(getenv("GAZ_HEADS_2STREAMS") && atoi(getenv("GAZ_HEADS_2STREAMS")) == 0);
+            hipStream_t sv = s;
+            if (two) {
+                if (!side_stream) { hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking); hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ev_join, hipEventDisableTiming); }
+                hipEventRecord(ev_fork, s); hipStreamWaitEvent(side_stream, ev_fork, 0); sv = side_stream;
+            }
             {
                 ConvSmallArgs c; c.in = PH; c.w = g("p.c2.w"); c.bias = g("p.c2.bias"); c.flat = pfeat; c.fs = g("p.bn2.scale"); c.ft = g("p.bn2.shift");
                 c.act = NACT_RELU; c.M = M; c.H = H; c.W = W;
                 hipLaunchKernelGGL((k_conv_small<8, 3>), dim3((M + 255) / 256), dim3(256), 0, s, c);
                 c.in = VH; c.w = g("v.c2.w"); c.bias = g("v.c2.bias"); c.flat = vfeat; c.fs = g("v.bn2.scale"); c.ft = g("v.bn2.shift");
-                hipLaunchKernelGGL((k_conv_small<4, 1>), dim3((M + 255) / 256), dim3(256), 0, s, c);
+                hipLaunchKernelGGL((k_conv_small<4, 1>), dim3((M + 255) / 256), dim3(256), 0, sv, c);
             }
+            dense(sv, vfeat, "v.d1.w", g("v.d1.scale"), g("v.d1.shift"), vd1, n, HW * 4, 256, NACT_RELU);
+            dense(sv, vd1, "v.d2.w", g("v.d2.scale"), g("v.d2.shift"), vd2, n, 256, 128, NACT_RELU);
+            dense(sv, vd2, "v.d3.w", nullptr, g("v.d3.bias"), value, n, 128, 1, NACT_TANH);
+            if (two) hipEventRecord(ev_join, side_stream);
             dense(s, pfeat, "p.d1.w", g("p.d1.scale"), g("p.d1.shift"), pd1, n, HW * 8, 512, NACT_RELU);
             dense(s, pd1, "p.d2.w", nullptr, g("p.d2.bias"), plog, n, 512, A, NACT_NONE);
-            dense(s, vfeat, "v.d1.w", g("v.d1.scale"), g("v.d1.shift"), vd1, n, HW * 4, 256, NACT_RELU);
-            dense(s, vd1, "v.d2.w", g("v.d2.scale"), g("v.d2.shift"), vd2, n, 256, 128, NACT_RELU);
-            dense(s, vd2, "v.d3.w", nullptr, g("v.d3.bias"), value, n, 128, 1, NACT_TANH);
+            if (two) hipStreamWaitEvent(s, ev_join, 0);
         } else {
             conv_direct(s, X, g("p.c.w"), F, 8, 1, g("p.c.scale"), g("p.c.shift"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, pfeat, nullptr, nullptr, NACT_NONE, M);
             conv_direct(s, X, g("v.c.w"), F, 4, 1, g("v.c.scale"), g("v.c.shift"), nullptr, nullptr, 0, nullptr, nullptr, nullptr, vfeat, nullptr, nullptr, NACT_NONE, M);
