@@ -1,5 +1,7 @@
 // puct_core.hpp — the PUCT self-play wave kernel: select / expand / backup, Dirichlet noise, move
-// sampling, re-rooting and the Self_Play per-game state machine, one wavefront per game.
+// sampling, re-rooting and the Self_Play per-game state machine.  A game is owned by a TEAM of lanes (wave.hpp): the whole
+// wavefront for Gomoku, a 16-lane row — four games per wavefront — for Connect4 / TicTacToe; everything below is written
+// against tlane / tballot / team_argmax, so the same source serves both (and the one-lane host emulation of tests/emu).
 //
 // Reference path replaced (all file:line under /root/reference):
 //   MCTS._get_best_PUCT_score_index  MCTS.py:172-191   -> best_puct_slot()       (K1)

@@ -1,8 +1,8 @@
 // wave.hpp — wavefront primitives for the tree kernels (gfx950, wave64).
 //
-// One wavefront (64 lanes) owns one game: control flow is wave-uniform, lanes fan out over the children
-// of a node (PUCT scoring, wave argmax), over candidate actions (terminal probe), over gamma variates
-// (Dirichlet noise) and over path levels (backup).  All cross-lane traffic is __shfl / __ballot (DPP /
+// A TEAM of lanes owns one game (the whole wavefront, or a 16-lane row: four games per wavefront, see "Teams" below): control flow
+// is uniform within the team, lanes fan out over the children of a node (PUCT scoring, team argmax), over candidate actions
+// (terminal probe), over gamma variates (Dirichlet noise) and over path levels (backup).  All cross-lane traffic is __shfl / __ballot (DPP /
 // ds_bpermute, no LDS round trip) plus a small per-wave LDS scratch.
 //
 // GAZ_HOST_EMU builds the very same device functions for the CPU with a wave of ONE lane (every
