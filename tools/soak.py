@@ -27,6 +27,9 @@ def run(game, search, G, iters, max_actions, waves, cache, check):
     return bad
 
 t0 = time.time(); bad = 0
+# round 2: without the evaluation cache the PUCT kernel of the small boards runs four games per wavefront (16-lane teams)
+bad += run("Connect4", SEARCH_PUCT, 1024, 60, 42, 6000, 0, 600)
+bad += run("TicTacToe", SEARCH_PUCT, 512, 30, 9, 2000, 0, 600)
 bad += run("Connect4", SEARCH_PUCT, 1024, 60, 42, 6000, 20, 600)
 bad += run("Connect4", SEARCH_GUMBEL, 1024, 32, 42, 4000, 20, 600)
 bad += run("TicTacToe", SEARCH_PUCT, 512, 30, 9, 2000, 16, 600)
