@@ -748,6 +748,8 @@ struct GenericEvaluator : Evaluator {
     bool fused = true, block0_fused = false, block0_inplace = false; int n_cus = 256, fused_blocks = 0;
     hipStream_t side_stream = 0; hipEvent_t ev_fork = 0, ev_join = 0;     // value head next to the policy head (Gomoku)   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
     bool trunk = true, trunk_m16 = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
+    // ... or block 0 INSIDE that launch (trunk.hpp B0; GAZ_BLOCK0_IN_TRUNK=0: k_block0 ahead of it): block 0's 29 slices + the blocks' 18 each
+    bool block0_in_trunk = true; bf16_t* trunk_w0 = nullptr; float* trunk_prm0 = nullptr;
     bf16_t* stem_frag = nullptr;
 
     ~GenericEvaluator() override {
@@ -847,6 +849,21 @@ struct GenericEvaluator : Evaluator {
                 const char* names[5] = {".bn1.scale", ".bn1.shift", ".conv1.scale", ".conv1.shift", ".conv2.bias"};
                 for (int k = 0; k < 5; ++k) hipMemcpy(trunk_prm + ((size_t)(i - 1) * 5 + k) * 128, f32[b + names[k]], 128 * 4, hipMemcpyDeviceToDevice);
             }
+            if (ok && b16.count("block0.w29")) {     // block 0 inside the launch: its slices ahead of the blocks', its parameters as TrunkArgs::prm0
+                const size_t S0 = 29 * (size_t)F * F;
+                trunk_w0 = dalloc<bf16_t>(S0 + nb * WB); trunk_prm0 = dalloc<float>(1024);
+                ok = trunk_w0 && trunk_prm0; if (!ok) lerr = "hipMalloc";
+                if (ok) {
+                    hipMemcpy(trunk_w0, b16["block0.w29"], S0 * 2, hipMemcpyDeviceToDevice);
+                    hipMemcpy(trunk_w0 + S0, trunk_w, nb * WB * 2, hipMemcpyDeviceToDevice);
+                    std::vector<float> h(1024, 0.0f);
+                    const float* b2 = by["block0.conv2.bias"]->data; const float* bp = by["block0.proj.bias"]->data;
+                    memcpy(&h[0], by["block0.bn1.scale"]->data, 256 * 4); memcpy(&h[256], by["block0.bn1.shift"]->data, 256 * 4);
+                    memcpy(&h[640], by["block0.conv1.scale"]->data, 128 * 4); memcpy(&h[768], by["block0.conv1.shift"]->data, 128 * 4);
+                    for (int c = 0; c < 128; ++c) h[896 + c] = b2[c] + bp[c];
+                    hipMemcpy(trunk_prm0, h.data(), 1024 * 4, hipMemcpyHostToDevice);
+                }
+            }
         }
         hipStreamSynchronize(s);
         if (!ok) { *err = lerr; return 1; }
@@ -920,6 +937,13 @@ struct GenericEvaluator : Evaluator {
         for (int i = 0; i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i), nb = "block" + std::to_string(i + 1);
             const bool first = i == 0, last = i + 1 == blocks;
+            if (fuse && first && block0_in_trunk && trunk && trunk_m16 && trunk_w0 && HW <= 256) {      // the whole trunk, block 0 included, in one launch
+                TrunkArgs t; memset(&t, 0, sizeof(t));
+                t.x0 = X0; t.prm0 = trunk_prm0; t.xout = Hh; t.w = trunk_w0; t.prm = trunk_prm; t.M = M; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
+                hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), dim3(n), dim3(512), trunk_lds_bytes(256), s, t);
+                cur = Hh; fused_blocks += blocks; block0_fused = true;
+                break;
+            }
             if (fuse && first && b16.count(b + ".w29")) {          // the 256 -> 128 block with its projection, one kernel (k_block0)
                 Block0Args r; memset(&r, 0, sizeof(r));
                 r.a0 = block0_inplace ? nullptr : A0; r.x0 = X0; r.xout = X; r.w = b16[b + ".w29"]; r.s2 = g(b + ".conv1.scale"); r.t2 = g(b + ".conv1.shift");
@@ -1038,6 +1062,8 @@ struct GenericEvaluator : Evaluator {
         if (!gomoku) { *flops = 0; return ""; }
         const bool fz = fused && blocks > 1;
         *flops = fz ? 2 * conv : conv;
+        if (fz && trunk && trunk_w && trunk_m16 && block0_in_trunk && trunk_w0)
+            return "k_trunk<8 waves, B0> (the whole trunk in one launch, block 0 with its projection included; priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16)";
         if (fz && trunk && trunk_w) return trunk_m16 ? "k_trunk<RESG, 8 waves> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16)"
                                                      : "k_trunk<4,2,RESG> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_32x32x16_bf16)";
         return fz ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
@@ -1055,6 +1081,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     e->fused = !(getenv("GAZ_FUSED") && atoi(getenv("GAZ_FUSED")) == 0);
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     e->trunk_m16 = !(getenv("GAZ_TRUNK_M16") && atoi(getenv("GAZ_TRUNK_M16")) == 0);
+    e->block0_in_trunk = !(getenv("GAZ_BLOCK0_IN_TRUNK") && atoi(getenv("GAZ_BLOCK0_IN_TRUNK")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
@@ -1068,6 +1095,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     hipFuncSetAttribute((const void*)k_conv_head32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_lds_bytes());
     hipFuncSetAttribute((const void*)(k_trunk<4, 2, 4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256, true));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256));
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

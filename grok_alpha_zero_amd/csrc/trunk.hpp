@@ -34,6 +34,11 @@ struct TrunkArgs {
     // fused tree + trunk launch (fused.hip): board b's planes are valid once ready[b] has reached `epoch` (written by the tree team
     // of game b in this very launch); null = the planes were complete before the launch
     const unsigned* ready; unsigned epoch;
+    // B0 (Gomoku, round 2): the FIRST block of the network — 256 stem channels -> 128 with a 1x1 projection on the skip path
+    // (Net/ResNet/ResNet_Block.py:21-33) — runs inside this launch too, ahead of blocks 1..: x0 = raw stem output [M][256];
+    // w then starts with block 0's 29 slices (conv1 channels 0-127 | 128-255, conv2, projection low | high); prm0 [1024] =
+    // bn1 scale [256] | bn1 shift [256] | pad [128] | conv1 scale [128] | conv1 shift [128] | conv2 bias + projection bias [128]
+    const bf16_t* x0; const float* prm0;
     // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
     const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
@@ -78,8 +83,10 @@ template <bool M16> __device__ __forceinline__ int swz_inv(int sp, int row) { re
 // re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
 // NW = waves per workgroup (4; 8 for the 256-row Gomoku tile: WM = 4 waves down the cells, one workgroup per CU with both images in LDS).
-template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4>
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false>
 __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
+    static_assert(!B0 || (M16 && !STEM && !HEADS && !RESG), "block 0 inside the launch: 16x16x32 build with both images in LDS");
+    constexpr int SL0 = B0 ? 29 : 0;                // weight slices of block 0 ahead of the regular blocks' 18 each
     constexpr int BN = 128, SLOTS = 16, WM = NW / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS, THREADS = 64 * NW;
     static_assert(NW == 4 || (!STEM && !HEADS), "stem / heads phases assume four waves");
     static_assert(KS % RING == 0, "ring slot must not depend on the tap");
@@ -100,11 +107,22 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lhi = lane >> 5;
     const int HW = a.H * a.W;
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
-    const int last_slice = a.nblocks * 18 - 1;
+    const int last_slice = SL0 + a.nblocks * 18 - 1;
     TR_STAMP(0);
 
     constexpr int n_slots = ROWS * SLOTS;
-    if (!STEM) {
+    // B0: image row q <-> global row m0 + q of channels [128 half, 128 half + 128) of the 256-channel stem output, into the OPERAND image
+    auto load_x0_half = [&](int half) {
+        const uint4* x04 = reinterpret_cast<const uint4*>(a.x0);
+        for (int base = wave * 64; base < n_slots; base += THREADS) {
+            const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
+            long gr = m0 + lr;
+            gr = gr >= a.M ? (long)a.M - 1 : gr;
+            __builtin_amdgcn_global_load_lds((const void*)(x04 + gr * (2 * SLOTS) + half * SLOTS + swz_inv<M16>(sp, lr)), (lds_ptr_t)(As + base), 16, 0, 0);
+        }
+    };
+    if (B0) load_x0_half(0);
+    if (!STEM && !B0) {
     // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
     for (int base = wave * 64; base < n_slots; base += THREADS) {
         const int i = base + lane, lr = i / SLOTS, sp = i % SLOTS;
@@ -116,7 +134,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     if (tid < TR_ZROWS * SLOTS) As[ZROW * SLOTS + tid] = make_uint4(0, 0, 0, 0);
     const float4* prm4 = reinterpret_cast<const float4*>(a.prm);
     float4* Ps4 = reinterpret_cast<float4*>(Ps);
-    if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
+    if (B0) { for (int i = tid; i < 256; i += THREADS) Ps4[i] = reinterpret_cast<const float4*>(a.prm0)[i]; }   // block 0's parameters fill both sets
+    else if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
     if (STEM && tid < 32) Ps4[TR_PRM / 4 + tid] = reinterpret_cast<const float4*>(a.stem_shift)[tid];      // the idle parameter set holds the stem's shift
 
     // B ring as in k_resblock3: fragment of global k-step g = slice * 8 + ks in bfr[g % RING]; the slices of ALL blocks are one array
@@ -223,6 +242,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                     const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t.w, 0.0f);
                     *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
                 }
+    } else if (B0) {
+        // the operand of conv1 is made further down (preact_half), half by half
     } else {
     // ---- block 0's operand: As = relu(x * s1 + t1)
     {
@@ -292,6 +313,128 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     typedef const __attribute__((address_space(3))) u32x4_t* lds_u4_t;
     const unsigned ldsb = (unsigned)(size_t)(lds_ptr_t)As;
     if (ldsb & 255u) __builtin_trap();
+    int pb[NC], pbn[NC];                            // byte address of k-group lq of k-step 0 of this lane's operand row
+    auto tap_rows = [&](int tap, int (&o)[NC]) {
+        const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            const bool ok = (cmask[t] >> tap) & 1u;
+            const int ar = ok ? crow[t] + off : ZROW + ((crow[t] + off) & 15);
+            o[t] = (int)ldsb + ar * 256 + (swz_slot<true>(lq, ar) << 4);          // k-step ks: ^ (ks << 5), see below
+        }
+    };
+    u32x4_t cfr[2][NC];                             // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
+    auto zero_acc16 = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < NCH; ++ct)
+#pragma unroll
+            for (int t = 0; t < NC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc16[ct][t][r] = 0.0f;
+    };
+    // taps [tap0, tap0 + ntaps) of the 3x3 stencil over the operand image, weight slice sl0 + i for the i-th of them; accumulates
+    auto conv_taps = [&](const int sl0, const int tap0, const int ntaps) {
+        tap_rows(tap0, pb);
+#pragma unroll
+        for (int t = 0; t < NC; ++t) cfr[0][t] = *(lds_u4_t)(unsigned)pb[t];
+#pragma unroll 1
+        for (int i = 0; i < ntaps; ++i) {
+            const int sl = sl0 + i;
+            const int nsl = sl < last_slice ? sl + 1 : sl;
+            tap_rows(i + 1 < ntaps ? tap0 + i + 1 : tap0 + i, pbn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+#pragma unroll
+                for (int ct = 0; ct < NCH / 2; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+                // the next k-step's reads in the middle of this one's MFMAs: this k-step's fragments are still live, so they cannot
+                // be allocated over them (behind the last MFMA the scheduler does exactly that: prefetch distance zero), and they
+                // issue in the shadow of the MFMAs above
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+                    cfr[(ks + 1) & 1][t] = *(lds_u4_t)(unsigned)((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 5));      // slot of k-group 4 ks + lq = slot of lq ^ (2 ks)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = NCH / 2; ct < NCH; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);    // the next slice's k-step ks; the very last slice re-reads itself
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t) pb[t] = pbn[t];
+        }
+    };
+    if constexpr (B0) {
+        // ---- block 0 (256 -> 128 with a projection): x_out = conv2(relu(bn2(conv1(relu(bn1(x0)))))) + proj(x0) + (b2 + bp).  The 256-channel
+        // operands pass through the 128-channel operand image in halves; conv2 and the projection share ONE accumulator.
+        auto preact_half = [&](int half) {          // in place: slot sp of row lr holds channels 128 half + 8 swz_inv(sp, lr) ..+7
+            for (int i = tid; i < n_slots; i += THREADS) {
+                const int lr = i / SLOTS, sp = i % SLOTS, c0 = half * 128 + swz_inv<true>(sp, lr) * 8;
+                const uint4 v = As[i];
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = fmaxf(__uint_as_float(w[j] << 16) * Ps[c0 + 2 * j] + Ps[256 + c0 + 2 * j], 0.0f);
+                    const float hi = fmaxf(__uint_as_float(w[j] & 0xFFFF0000u) * Ps[c0 + 2 * j + 1] + Ps[256 + c0 + 2 * j + 1], 0.0f);
+                    w[j] = pack_bf16(lo, hi);
+                }
+                As[i] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        };
+        // five passes over the operand image, ONE copy of the tap loop: conv1 over the pre-activated low / high input half, conv2 over
+        // h, the skip path's 1x1 projection (centre tap) over the raw low / high half
+#pragma unroll 1
+        for (int ph = 0; ph < 5; ++ph) {
+            if (ph > 0) __syncthreads();            // every wave is done with the previous image
+            if (ph == 2) {                          // block 0's bn1 vectors (parameter set 0) are free: the first regular block's parameters
+                if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
+#pragma unroll
+                for (int ct = 0; ct < NCH; ++ct) {  // h = relu(acc * s2 + t2) as bf16 over the operand image
+                    const int c0 = wn * TN * 32 + ct * 16 + 4 * lq;
+                    const float4 sc = *reinterpret_cast<const float4*>(&Ps[640 + c0]);
+                    const float4 t4 = *reinterpret_cast<const float4*>(&Ps[768 + c0]);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) {
+                        const float v0 = fmaxf(acc16[ct][t][0] * sc.x + t4.x, 0.0f), v1 = fmaxf(acc16[ct][t][1] * sc.y + t4.y, 0.0f);
+                        const float v2 = fmaxf(acc16[ct][t][2] * sc.z + t4.z, 0.0f), v3 = fmaxf(acc16[ct][t][3] * sc.w + t4.w, 0.0f);
+                        *reinterpret_cast<uint2*>(Ab + off16(ct, t)) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                    }
+                }
+            } else if (ph > 0) {
+                load_x0_half(ph == 3 ? 0 : 1);      // ph 1: high half; ph 3 / 4: the raw stem output again, low / high
+                __syncthreads();
+            }
+            if (ph < 2) { preact_half(ph); }
+            __syncthreads();
+            if (ph == 0 || ph == 2) zero_acc16();
+            conv_taps(ph < 3 ? 9 * ph : 24 + ph, ph < 3 ? 0 : 4, ph < 3 ? 9 : 1);
+        }
+        __syncthreads();                            // every wave is done with the image
+#pragma unroll
+        for (int ct = 0; ct < NCH; ++ct) {          // x = bf16(acc + (b2 + bp)) -> x image; the next block's operand relu(x s1 + t1) -> operand image
+            const int c0 = wn * TN * 32 + ct * 16 + 4 * lq;
+            const float4 b = *reinterpret_cast<const float4*>(&Ps[896 + c0]);
+            const float4 sc = *reinterpret_cast<const float4*>(&Ps[c0]);
+            const float4 t4 = *reinterpret_cast<const float4*>(&Ps[128 + c0]);
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const int o = off16(ct, t);
+                const uint2 xn = make_uint2(pack_bf16(acc16[ct][t][0] + b.x, acc16[ct][t][1] + b.y), pack_bf16(acc16[ct][t][2] + b.z, acc16[ct][t][3] + b.w));
+                *reinterpret_cast<uint2*>(Xb + o) = xn;
+                const float a0 = fmaxf(__uint_as_float(xn.x << 16) * sc.x + t4.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * sc.y + t4.y, 0.0f);
+                const float a2 = fmaxf(__uint_as_float(xn.y << 16) * sc.z + t4.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * sc.w + t4.w, 0.0f);
+                *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -301,59 +444,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         if (more && tid < TR_PRM / 4) pnext = prm4[(blk + 1) * (TR_PRM / 4) + tid];
 #pragma unroll
         for (int conv = 0; conv < 2; ++conv) {
-#pragma unroll
-            for (int ct = 0; ct < NCH; ++ct)
-#pragma unroll
-                for (int t = 0; t < NC; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc16[ct][t][r] = 0.0f;
-            int pb[NC], pbn[NC];                    // byte address of k-group lq of k-step 0 of this lane's operand row
-            auto tap_rows = [&](int tap, int (&o)[NC]) {
-                const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
-#pragma unroll
-                for (int t = 0; t < NC; ++t) {
-                    const bool ok = (cmask[t] >> tap) & 1u;
-                    const int ar = ok ? crow[t] + off : ZROW + ((crow[t] + off) & 15);
-                    o[t] = (int)ldsb + ar * 256 + (swz_slot<true>(lq, ar) << 4);          // k-step ks: ^ (ks << 5), see below
-                }
-            };
-            u32x4_t cfr[2][NC];                     // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
-            tap_rows(0, pb);
-#pragma unroll
-            for (int t = 0; t < NC; ++t) cfr[0][t] = *(lds_u4_t)(unsigned)pb[t];
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                const int sl = blk * 18 + conv * 9 + tap;
-                const int nsl = sl < last_slice ? sl + 1 : sl;
-                tap_rows(tap < 8 ? tap + 1 : 8, pbn);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KS32; ++ks) {
-#pragma unroll
-                    for (int ct = 0; ct < NCH / 2; ++ct)
-#pragma unroll
-                        for (int t = 0; t < NC; ++t)
-                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
-                    // the next k-step's reads in the middle of this one's MFMAs: this k-step's fragments are still live, so they cannot
-                    // be allocated over them (behind the last MFMA the scheduler does exactly that: prefetch distance zero), and they
-                    // issue in the shadow of the MFMAs above
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < NC; ++t)
-                        cfr[(ks + 1) & 1][t] = *(lds_u4_t)(unsigned)((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 5));      // slot of k-group 4 ks + lq = slot of lq ^ (2 ks)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ct = NCH / 2; ct < NCH; ++ct)
-#pragma unroll
-                        for (int t = 0; t < NC; ++t)
-                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
-#pragma unroll
-                    for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);    // the next slice's k-step ks; the very last slice re-reads itself
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int t = 0; t < NC; ++t) pb[t] = pbn[t];
-            }
+            zero_acc16();
+            conv_taps(SL0 + blk * 18 + conv * 9, 0, 9);
             if (blk < 10) TR_STAMP(3 + 6 * blk + 3 * conv);
             if (conv == 0) {
                 if (more && tid < TR_PRM / 4) Ps4[((blk + 1) & 1) * (TR_PRM / 4) + tid] = pnext;
@@ -618,9 +710,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4>
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false>
 __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of

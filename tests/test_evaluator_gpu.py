@@ -113,7 +113,8 @@ def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
 def test_gomoku_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
     """Gomoku: k_block0 + ONE k_trunk launch for blocks 1.. against k_block0 + one k_resblock3 launch per block (GAZ_TRUNK=0).  The
     32x32x16 build of the trunk launch (GAZ_TRUNK_M16=0: one board per 4-wave workgroup, residual stream through L2, trunk.hpp RESG) is
-    the per-block arithmetic bit for bit; the default 16x16x32 build (8-wave workgroup, both images in LDS) within bf16 tolerance."""
+    the per-block arithmetic bit for bit; the 16x16x32 builds (8-wave workgroup, both images in LDS) within bf16 tolerance: the default
+    with block 0 inside the launch (trunk.hpp B0) and GAZ_BLOCK0_IN_TRUNK=0 with k_block0 ahead of it."""
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
     from grok_alpha_zero_amd.net import NETS
     rng = np.random.default_rng(blocks + n)
@@ -121,18 +122,20 @@ def test_gomoku_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
     net.randomize_bn()
     x = rng.integers(-1, 2, size=(n, 15, 15, 2)).astype(np.int8)
     outs = []
-    for trunk, m16 in (("1", "0"), ("0", "0"), ("1", "1")):
+    for trunk, m16, b0 in (("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("1", "1", "0")):
         monkeypatch.setenv("GAZ_TRUNK", trunk)
         monkeypatch.setenv("GAZ_TRUNK_M16", m16)
+        monkeypatch.setenv("GAZ_BLOCK0_IN_TRUNK", b0)
         eng = SelfPlayEngine("Gomoku", max(n, 8), 50, 150, 2, 1, 1.25, 1.0, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks, net_filters=128,
                              ring_capacity=0)
         eng.load_weights(net.export_engine_weights())
         outs.append(eng.evaluate(x)[:2])
         eng.close()
-    assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[2][0]).all()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-    dp = np.abs(outs[2][0] - outs[0][0]); dv = np.abs(outs[2][1] - outs[0][1])
-    assert dp.max() <= 6e-2 and dp.mean() <= 3e-3 and dv.max() <= 0.15 and dv.mean() <= 1e-2, (dp.max(), dp.mean(), dv.max(), dv.mean())
+    for o in outs[2:]:
+        assert np.isfinite(outs[0][0]).all() and np.isfinite(o[0]).all()
+        dp = np.abs(o[0] - outs[0][0]); dv = np.abs(o[1] - outs[0][1])
+        assert dp.max() <= 6e-2 and dp.mean() <= 3e-3 and dv.max() <= 0.15 and dv.mean() <= 1e-2, (dp.max(), dp.mean(), dv.max(), dv.mean())
 
 
 def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
@@ -366,10 +369,11 @@ def test_fused_tree_and_trunk_launch_gives_identical_games():
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
 
 
-@pytest.mark.parametrize("blocks,active,n", [(2, 1, 23), (2, -1, 9), (10, 1, 12), (10, 5, 12), (10, 9, 33)])
-def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n):
-    """The Gomoku network's kernels (k_stem_mfma, k_block0 with its in-LDS pre-activation and the projection accumulated into conv2,
-    the 8-wave k_trunk for blocks 1.., k_conv_head32, k_conv_small, the fp32 dense chain) against GomokuNet.forward_engine_numerics —
+@pytest.mark.parametrize("blocks,active,n,b0", [(2, 1, 23, "1"), (2, -1, 9, "1"), (2, -1, 9, "0"), (10, 1, 12, "1"), (10, 5, 12, "1"), (10, 9, 33, "1"), (10, 9, 33, "0")])
+def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n, b0, monkeypatch):
+    """The Gomoku network's kernels (k_stem_mfma; block 0 with its in-LDS pre-activation and the projection accumulated into conv2 —
+    inside the 8-wave k_trunk launch (b0 = "1", the default) or as k_block0 ahead of it (GAZ_BLOCK0_IN_TRUNK=0); the 8-wave k_trunk for
+    blocks 1.., k_conv_head32, k_conv_small, the fp32 dense chain) against GomokuNet.forward_engine_numerics —
     the same network with a bf16 rounding at exactly the points these kernels round.  Block 0 (it carries the 256 -> 128 projection)
     is always live; of blocks 1.. ONE is active at a time (the others have zero convolution weights and conv2 bias and pass the
     residual stream through bit for bit), so every slice of the 10-block weight stream is checked with only a few rounding stages
@@ -381,6 +385,7 @@ def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, acti
     import torch
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
     from grok_alpha_zero_amd.net import GomokuNet
+    monkeypatch.setenv("GAZ_BLOCK0_IN_TRUNK", b0)
     rng = np.random.default_rng(blocks * 100 + n)
     x = rng.integers(-1, 2, size=(n, 15, 15, 2)).astype(np.int8)
     x[..., 0] = rng.choice([-1, 1], size=(n, 1, 1))
