@@ -25,7 +25,7 @@ struct Evaluator {
     virtual int round_rows() const { return 0; }                  // positions one full round of the trunk kernel's tiles covers
     virtual void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int p0) { (void)s; (void)in; (void)n; (void)timing; (void)p0; }
     virtual void forward_heads(hipStream_t s, float* policy, float* value, int n, int p0) { (void)s; (void)policy; (void)value; (void)n; (void)p0; }
-    // fused tree + trunk launch (fused.hip): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
+    // fused tree + trunk launch (resnet.hip k_wave_trunk): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
     // planes of board b are valid once ready[b] == epoch.  Null = this evaluator / configuration cannot be fused.
     virtual const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) { (void)in; (void)n; (void)p0; (void)ready; (void)epoch; return nullptr; }
     virtual bool ready() const { return true; }
@@ -79,7 +79,7 @@ struct HashEvaluator : Evaluator {
 };
 
 Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err);
-// fused.hip: ONE launch = the PUCT tree step of Connect4 games [g0, g1) (16-lane teams) + the trunk kernel of their leaf rows.
+// resnet.hip k_wave_trunk: ONE launch = the PUCT tree step of Connect4 games [g0, g1) (16-lane teams) + the trunk kernel of their leaf rows.
 // dev_params: DevParams<TeamGame<GAME_C4>> by value; plan: what Evaluator::trunk_plan returned.  false = not launched.
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
 

@@ -71,7 +71,7 @@ template <class G> struct DevParams {
     const double* puct_table;  // [PUCT_TABLE_N][2]: sqrt(pv), c_init + ln((pv + c_base + 1) / c_base)
     unsigned long long* prof;  // diagnostic (GAZ_TREE_PROF=1): [n_games][8] shader-clock cycles per phase of the PUCT kernel, else null
     int32_t* error;            // first error code, 0 = none
-    // fused tree + trunk launch (fused.hip): a game's team publishes "my leaf row of this wave is in memory" so that the trunk
+    // fused tree + trunk launch (resnet.hip k_wave_trunk): a game's team publishes "my leaf row of this wave is in memory" so that the trunk
     // workgroups of the SAME launch can start on their boards while slower games are still searching.  Null = plain launches.
     uint32_t* done_flag;       // [n_games] epoch of the last launch that finished the game's tree step
     uint32_t wave_epoch;

@@ -31,7 +31,7 @@ struct TrunkArgs {
     unsigned long long* stamps;                   // diagnostic (GAZ_TRUNK_STAMPS, tools/trunk_stamps.py): [workgroup][128] or null
     // STEM: the stem convolution (k_stem_mfma's operands) computed straight into the images instead of reading xin
     const int8_t* planes; const uint4* stem_frag; const float* stem_shift;        // [M][4] int8; [6 k-steps][2][128] x 8 bf16 (hi | lo); [128]
-    // fused tree + trunk launch (fused.hip): board b's planes are valid once ready[b] has reached `epoch` (written by the tree team
+    // fused tree + trunk launch (resnet.hip k_wave_trunk): board b's planes are valid once ready[b] has reached `epoch` (written by the tree team
     // of game b in this very launch); null = the planes were complete before the launch
     const unsigned* ready; unsigned epoch;
     // B0 (Gomoku, round 2): the FIRST block of the network — 256 stem channels -> 128 with a 1x1 projection on the skip path
@@ -44,7 +44,7 @@ struct TrunkArgs {
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
 };
 
-// what ResNetEvaluator::forward_trunk launches, as data: used by the fused tree + trunk launch (fused.hip)
+// what ResNetEvaluator::forward_trunk launches, as data: used by the fused tree + trunk launch (resnet.hip k_wave_trunk)
 struct TrunkLaunchPlan { TrunkArgs args; int nwg; int mix; unsigned lds_bytes; };
 
 __device__ __forceinline__ float gelu_as(float v) {         // x * Phi(x), Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8)
