@@ -79,6 +79,31 @@ def test_rows_are_batch_independent():
     eng.close()
 
 
+@pytest.mark.parametrize("game,blocks,filters,n", [("Gomoku", 3, 128, 37), ("TicTacToe", 2, 64, 150)])
+def test_rows_are_batch_independent_generic_networks(game, blocks, filters, n):
+    """The same for the Gomoku network (block 0 inside the 8-wave trunk launch, one board per workgroup; 32-row dense tiles) and the
+    TicTacToe network: permuted and truncated batches and single rows give the same bits."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    rng = np.random.default_rng(n)
+    net = NETS[game](blocks).eval()
+    net.randomize_bn()
+    eng = SelfPlayEngine(game, n, 50, 9 if game == "TicTacToe" else 150, 2, 1, 1.25, 1.0, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks,
+                         net_filters=filters, ring_capacity=0)
+    eng.load_weights(net.export_engine_weights())
+    x = rng.integers(-1, 2, size=(n, net.H, net.W, net.C)).astype(np.int8)
+    p1, v1, _ = eng.evaluate(x)
+    perm = rng.permutation(n)
+    p2, v2, _ = eng.evaluate(x[perm])
+    assert np.isfinite(p1).all() and np.array_equal(p1[perm], p2) and np.array_equal(v1[perm], v2)
+    p3, v3, _ = eng.evaluate(x[:11])
+    assert np.array_equal(p1[:11], p3) and np.array_equal(v1[:11], v3)
+    for i in (0, n // 2, n - 1):
+        p4, v4, _ = eng.evaluate(x[i:i + 1])
+        assert np.array_equal(p1[i], p4[0]) and v1[i] == v4[0]
+    eng.close()
+
+
 @pytest.mark.parametrize("blocks,n", [(1, 5), (6, 334), (3, 4096)])
 def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
     """k_trunk / k_trunk_mix (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations
@@ -163,6 +188,39 @@ def test_search_with_resnet_matches_oracle_with_same_outputs(oracle):
         np.testing.assert_array_equal(r["actions"], o["actions"])
         np.testing.assert_array_equal(r["root_N"], o["root_N"])
         np.testing.assert_array_equal(r["root_W"], o["root_W"])
+    eng.close(); probe.close()
+
+
+def test_gomoku_search_with_resnet_matches_oracle_with_same_outputs(oracle):
+    """The same composition check for Gomoku: the one-game-per-wavefront tree kernel + the Gomoku network (stem, block 0 inside the
+    trunk launch, heads on two streams) against the oracle served by evaluate() on single rows."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    G, iters, plies = 5, 36, 3         # a Gomoku move runs >= 3 x (legal moves) simulations when the limit is below that count (MCTS.py:545-546): ~670 per ply
+    net = NETS["Gomoku"](2).eval()
+    net.randomize_bn()
+    w = net.export_engine_weights()
+    eng = SelfPlayEngine("Gomoku", G, iters, plies, 3, 2, 4.5, 0.05, seed=3, evaluator=EVAL_RESNET, net_blocks=2, net_filters=128, ring_capacity=4 * G)
+    probe = SelfPlayEngine("Gomoku", 8, 1, plies, 3, 2, 4.5, 0.05, seed=0, evaluator=EVAL_RESNET, net_blocks=2, net_filters=128, ring_capacity=0)
+    eng.load_weights(w); probe.load_weights(w)
+    recs = []
+    for _ in range(100):
+        eng.run_waves(64); recs += eng.drain_finished()
+        if len({r["slot"] for r in recs if r["game_seq"] == 0}) == G:
+            break
+    first = {r["slot"]: r for r in recs if r["game_seq"] == 0}
+    assert len(first) == G
+
+    def ev(state):
+        p, v, _ = probe.evaluate(state[None])
+        return p[0], v[0]
+    for slot in (0, 4):
+        o = oracle.selfplay_game("Gomoku", iters, plies, 3, 2, 4.5, 0.05, 3, slot, 0, evaluator=ev)
+        r = first[slot]
+        np.testing.assert_array_equal(r["actions"], o["actions"])
+        np.testing.assert_array_equal(r["root_N"], o["root_N"])
+        np.testing.assert_array_equal(r["root_W"], o["root_W"])
+        np.testing.assert_array_equal(r["policies"], o["policies"])
     eng.close(); probe.close()
 
 
