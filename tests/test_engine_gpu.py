@@ -268,6 +268,48 @@ def test_hip_gumbel_matches_oracle_many_games(oracle, game, G, n, max_actions, m
     eng.close()
 
 
+@pytest.mark.parametrize("game,G,iters,kw", [
+    ("Connect4", 192, 48, dict(create_new_root=True)),
+    ("Connect4", 192, 48, dict(c_puct_base=300.0)),
+    ("Connect4", 128, 40, dict(opening_actions=[(3, 0.5), (2, 0.25), (4, 0.25)])),
+    ("TicTacToe", 96, 30, dict(create_new_root=True, c_puct_base=50.0)),
+])
+def test_hip_puct_options_match_oracle_many_games(oracle, game, G, iters, kw):
+    """The PUCT self-play options at scale — create_new_root (no tree reuse, Self_Play.py:147-157), a non-default c_puct_base
+    (MCTS.py:172-191) and train_config["opening_actions"] (Self_Play.py:130-140) — on many concurrent games vs the oracle, bit-exact."""
+    ma, ef, es, c, alpha = (42, 8, 7, 2.5, 0.5) if game == "Connect4" else (9, 2, 1, 1.25, 1.0)
+    eng = _engine(game, G, iters, ma, ef, es, c, alpha, seed=99, hash_salt=21, slot_offset=7, ring_capacity=4 * G, **kw)
+    recs = _play_until(eng, lambda rs: len({(r["slot"], r["game_seq"]) for r in rs if r["game_seq"] < 2}) == 2 * G)
+    recs = [r for r in recs if r["game_seq"] < 2]
+    ora = oracle_many(oracle.selfplay_game, [((game, iters, ma, ef, es, c, alpha, 99, r["slot"], r["game_seq"]), dict(hash_salt=21, **kw)) for r in recs])
+    assert len(recs) == 2 * G
+    for r, o in zip(recs, ora):
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']} seq {r['game_seq']}")
+    eng.close()
+
+
+@pytest.mark.parametrize("G,n,m,stablemax,noise", [(256, 32, 7, True, True), (192, 24, 5, False, False), (96, 40, 7, True, False)])
+def test_hip_gumbel_variants_match_oracle_many_games(oracle, G, n, m, stablemax, noise):
+    """The Gumbel engine's two switches at scale — activation_fn = "stablemax" in the completed-Q selection (MCTS_Gumbel.py:77-99,
+    Self_Play.py:69) and use_gumbel_noise = False (MCTS_Gumbel.py:157,592) — on many concurrent Connect4 games vs the oracle, bit-exact
+    (the reference fixtures pin each switch on single games)."""
+    from grok_alpha_zero_amd.engine import SEARCH_GUMBEL
+    eng = _engine("Connect4", G, n, 42, 0, 0, 0.0, 0.0, seed=77, hash_salt=5, slot_offset=40, ring_capacity=4 * G, search=SEARCH_GUMBEL,
+                  gumbel_m=m, c_visit=50.0, c_scale=1.0, gumbel_stablemax=stablemax, use_gumbel_noise=noise)
+    recs = _play_until(eng, lambda rs: len({r["slot"] for r in rs if r["game_seq"] == 0}) == G)
+    first = [r for r in recs if r["game_seq"] == 0]
+    ora = oracle_many(oracle.selfplay_game_gumbel, [(("Connect4", n, 42, m, 50.0, 1.0, 77, r["slot"], 0), dict(hash_salt=5, stablemax=stablemax, gumbel_noise=noise))
+                                                      for r in first])
+    assert len(first) == G
+    for r, o in zip(first, ora):
+        assert r["T"] == o["T"] and r["winner"] == o["winner"]
+        for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {r['slot']}")
+    eng.close()
+
+
 def test_hip_reroot_compaction_matches_oracle(oracle):
     """Re-root compaction forced on for Connect4 (it is the default only for Gomoku): results must not change."""
     G, iters = 128, 50
