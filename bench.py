@@ -355,6 +355,14 @@ def main():
                         traffic_source=(f"{traffic_src}: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this command, "
                                         "not measured in this run") if traffic_src else None,
                         kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+            import re
+            m_issued = re.search(r"MFMA work issued = ([0-9.]+) of the counted FLOPs", kname)
+            if m_issued:                                    # the kernel skips exact-zero work: say how much of the counted FLOPs the matrix cores execute
+                roof["mfma_work_issued_share"] = float(m_issued.group(1))
+                roof["frac_of_peak_issued"] = roof["frac"] * float(m_issued.group(1))
+                roof["issued_note"] = ("achieved / frac price the ALGORITHMIC FLOPs of the dense 3x3 convolutions (SURVEY 8d); the kernel leaves out the MFMA tiles whose "
+                                       "16 cells all read zero padding on a tap (exact zeros, results bit-identical), so the matrix cores execute "
+                                       "mfma_work_issued_share of them: frac_of_peak_issued is the hardware rate, frac the useful rate")
             if tm_fused is not None and tm_fused["n_dominant"] > 0:
                 f_ms = tm_fused["ms_dominant"] / tm_fused["n_dominant"]
                 roof["measured_in"] = (f"a second timed segment of this run ({args.waves_per_step} waves, HIP events on every 8th) with the tree step and the "

@@ -460,6 +460,78 @@ __global__ __launch_bounds__(128) void k_tail(TailArgs a) {
     }
 }
 
+// [MFMA row of a workgroup's tile] -> image row (cell of the tile; rows >= boards * H * W are padding), for TrunkArgs::perm.  The tile is
+// `rows` MFMA rows = rows / 16 MFMA tiles; a wave computes `wave_rows` consecutive MFMA rows, and the kernel can let a wave's FIRST TWO MFMA
+// tiles sit out a tap when all 16 of their cells read zero padding there.  So: the cells of each board edge (y = 0, y = H - 1, x = 0,
+// x = W - 1; topped up with padding rows) become whole MFMA tiles — each sits out the three taps that look across its edge — dealt out
+// over the waves; leftover padding rows make all-padding tiles (they sit out every tap); every other cell keeps its natural order.  Inside
+// a tile the rows are ordered so that the two groups of eight lanes a ds_read_b128 serves together ({0-3, 12-15} and {4-11}) hit eight
+// different row & 7 (the image swizzle's conflict-free condition).  Connect4, three boards in 128 rows: four edge tiles, 30 of 36 tile-taps
+// per wave left (-16.7 % MFMAs); two boards in 96 rows: two edge tiles (-11 %); a Gomoku board in 256 rows: four edge tiles (-8.3 %).
+static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wave_rows) {
+    const int HW = H * W, cells = boards * HW, n_wr = rows / wave_rows, max_special = 2 * n_wr;
+    std::vector<uint8_t> none;
+    if (rows > 256 || rows % 16 || wave_rows % 16 || rows % wave_rows || cells > rows || wave_rows < 32) return none;
+    std::vector<char> used(rows, 0);
+    std::vector<int> pads;
+    for (int r = rows - 1; r >= cells; --r) pads.push_back(r);      // taken from the back: lowest padding row first
+    auto edges_of = [&](int c) { const int cell = c % HW, y = cell / W, x = cell % W; return (y == 0) + (y == H - 1) + (x == 0) + (x == W - 1); };
+    auto in_group = [&](int c, int g) { const int cell = c % HW, y = cell / W, x = cell % W; return g == 0 ? y == 0 : g == 1 ? y == H - 1 : g == 2 ? x == 0 : x == W - 1; };
+    std::vector<std::vector<int>> special;
+    for (int g = 0; g < 4 && (int)special.size() < max_special; ++g) {
+        std::vector<int> avail;
+        for (int pass = 1; pass <= 2; ++pass)                       // cells of this edge only first, corners (shared with another edge) last
+            for (int c = 0; c < cells; ++c) if (!used[c] && in_group(c, g) && (edges_of(c) == 1) == (pass == 1)) avail.push_back(c);
+        const int take = std::min<int>(16, (int)avail.size());
+        if (take == 0 || 16 - take > (int)pads.size()) continue;
+        std::vector<int> t(avail.begin(), avail.begin() + take);
+        while ((int)t.size() < 16) { t.push_back(pads.back()); pads.pop_back(); }
+        for (int r : t) used[r] = 1;
+        special.push_back(t);
+    }
+    while ((int)special.size() < max_special && pads.size() >= 16) {
+        std::vector<int> t;
+        for (int i = 0; i < 16; ++i) { t.push_back(pads.back()); pads.pop_back(); }
+        for (int r : t) used[r] = 1;
+        special.push_back(t);
+    }
+    // special tile k -> wave-row k % n_wr, MFMA tile k / n_wr of it; the other tiles take the remaining rows in natural order
+    std::vector<std::vector<int>> tiles(rows / 16);
+    for (size_t k = 0; k < special.size(); ++k) tiles[(k % n_wr) * (wave_rows / 16) + k / n_wr] = special[k];
+    int next = 0;
+    for (auto& t : tiles) {
+        if (!t.empty()) continue;
+        while ((int)t.size() < 16) { while (used[next]) ++next; t.push_back(next); used[next] = 1; }
+    }
+    std::vector<uint8_t> perm(rows);
+    const int P1[8] = {0, 1, 2, 3, 12, 13, 14, 15}, P2[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    for (size_t ti = 0; ti < tiles.size(); ++ti) {
+        std::vector<int> bucket[8], g1, g2;
+        for (int r : tiles[ti]) bucket[r & 7].push_back(r);
+        for (int res = 0; res < 8; ++res) if (!bucket[res].empty()) { g1.push_back(bucket[res].back()); bucket[res].pop_back(); }
+        for (int res = 0; res < 8; ++res) if (!bucket[res].empty() && g2.size() < 8) { g2.push_back(bucket[res].back()); bucket[res].pop_back(); }
+        for (int res = 0; res < 8; ++res) for (int r : bucket[res]) (g1.size() < 8 ? g1 : g2).push_back(r);
+        while (g1.size() > 8) { g2.push_back(g1.back()); g1.pop_back(); }
+        while (g2.size() > 8) { g1.push_back(g2.back()); g2.pop_back(); }
+        for (int i = 0; i < 8; ++i) { perm[ti * 16 + P1[i]] = (uint8_t)g1[i]; perm[ti * 16 + P2[i]] = (uint8_t)g2[i]; }
+    }
+    std::vector<char> seen(rows, 0);
+    for (int r = 0; r < rows; ++r) { if (seen[perm[r]]) return none; seen[perm[r]] = 1; }       // must be a bijection
+    return perm;
+}
+
+// taps (bit q = tap q of the 3x3 stencil) on which all 16 cells of MFMA tile `tile` of a permuted workgroup tile read zero padding
+static unsigned tile_sitout(const std::vector<uint8_t>& perm, int H, int W, int boards, int tile) {
+    unsigned m = 0x1FFu;
+    for (int i = 0; i < 16; ++i) {
+        const int r = perm[tile * 16 + i];
+        if (r >= boards * H * W) continue;          // padding row: reads zeros on every tap
+        const int cell = r % (H * W), y = cell / W, x = cell % W;
+        for (int q = 0; q < 9; ++q) { const int dy = q / 3 - 1, dx = q % 3 - 1; if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) m &= ~(1u << q); }
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------ host
 struct ResNetEvaluator : Evaluator {
     int H, W, C, A, HW, blocks, filters, nmax, logits;
@@ -474,6 +546,8 @@ struct ResNetEvaluator : Evaluator {
     bool trunk_whole = true;                        // ... including the stem and the heads' first convolution; GAZ_TRUNK_WHOLE=0 -> k_stem_mfma / k_conv_heads
     bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
     bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;
+    std::string dom_label;
+    uint8_t *perm_big = nullptr, *perm_small = nullptr;    // TrunkArgs::perm for the 128-row and the 96-row tile (tile_perm; GAZ_TILE_PERM=0: none)
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
     bool loaded = false;
@@ -535,6 +609,18 @@ struct ResNetEvaluator : Evaluator {
                 for (int k = 0; k < 5; ++k) hipMemcpy(trunk_prm + ((size_t)i * 5 + k) * 128, f32[b + names[k]], 128 * 4, hipMemcpyDeviceToDevice);
             }
         }
+        if (!(getenv("GAZ_TILE_PERM") && atoi(getenv("GAZ_TILE_PERM")) == 0) && !perm_big && 96 / HW >= 1) {
+            // the kernels' static sit-out masks (trunk.hpp conv9): 128-row tile = two wave rows (y = 0 | x = 0) and (y = H - 1 | x = W - 1); 96-row
+            // tile = one wave row (y = 0 | y = H - 1).  Both permutations must deliver exactly that, or neither is used.
+            const std::vector<uint8_t> pb = tile_perm(H, W, 128 / HW, 128, 64), ps = tile_perm(H, W, 96 / HW, 96, 96);
+            const unsigned want_big[4] = {0x007u, 0x049u, 0x1C0u, 0x124u}, want_small[2] = {0x007u, 0x1C0u};
+            bool ok = !pb.empty() && !ps.empty();
+            for (int wr = 0; ok && wr < 2; ++wr) for (int t = 0; t < 2; ++t) ok = ok && (tile_sitout(pb, H, W, 128 / HW, wr * 4 + t) & want_big[wr * 2 + t]) == want_big[wr * 2 + t];
+            for (int t = 0; ok && t < 2; ++t) ok = (tile_sitout(ps, H, W, 96 / HW, t) & want_small[t]) == want_small[t];
+            if (ok && (perm_big = dalloc<uint8_t>(pb.size())) && (perm_small = dalloc<uint8_t>(ps.size()))) {
+                hipMemcpy(perm_big, pb.data(), pb.size(), hipMemcpyHostToDevice); hipMemcpy(perm_small, ps.data(), ps.size(), hipMemcpyHostToDevice);
+            } else { perm_big = perm_small = nullptr; }
+        }
         if (!up_b16("heads.conv.w", 9LL * 32 * Fc) || !up_f32("heads.conv.bias", 32)) return 1;
         for (const char* pre : {"p", "v"}) {
             const std::string p = pre; const int nout = p == "p" ? A : 1;
@@ -572,7 +658,7 @@ struct ResNetEvaluator : Evaluator {
         const int M = n * HW;
         TrunkArgs& r = P.args; memset(&r, 0, sizeof(r));
         r.xin = this->X + (size_t)p0 * HW * 128; r.xout = this->X2 + (size_t)p0 * HW * 128; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
-        r.tile_rows = (128 / HW) * HW; r.stamps = nullptr;
+        r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small;
         r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
         r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
         r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"];
@@ -627,7 +713,7 @@ struct ResNetEvaluator : Evaluator {
         bf16_t* cur = X;
         if (use_trunk) {                            // every block in one kernel, k whole boards per workgroup (trunk.hpp)
             TrunkArgs r; memset(&r, 0, sizeof(r)); r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
-            r.tile_rows = (128 / HW) * HW; r.stamps = nullptr;
+            r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small;
             r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
             r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
             r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"]; r.p_feat = pfeat; r.v_feat = vfeat;
@@ -642,7 +728,8 @@ struct ResNetEvaluator : Evaluator {
             static const char* stamp_path = getenv("GAZ_TRUNK_STAMPS");    // diagnostic: phase stamps of the third launch -> file
             const bool stamp = stamp_path && ++stamp_calls == 3;
             if (stamp) { hipMalloc((void**)&r.stamps, (size_t)nwg * 128 * 8); hipMemsetAsync(r.stamps, 0, (size_t)nwg * 128 * 8, s); }
-            if (mix && trunk_m16) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            if (mix && trunk_m16 && r.perm && r.perm_small) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
+            else if (mix && trunk_m16) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else if (whole && trunk_m16) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true, false, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else if (mix) hipLaunchKernelGGL((k_trunk_mix<8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
             else if (whole) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, true, true>), dim3(nwg), dim3(TR_THREADS), trunk_lds_bytes(128), s, r);
@@ -725,6 +812,19 @@ struct ResNetEvaluator : Evaluator {
         *flops = fused ? 2 * conv : conv;
         if (fused && trunk) {
             *flops = 2 * conv * blocks;
+            if (trunk_whole && trunk_m16 && trunk_mix && perm_big && perm_small) {
+                // MFMA rows x taps actually issued / counted (n HW rows x 9 taps): 128-row tiles run 30 of 36 tile-taps per wave, 96-row tiles 48 of 54
+                const int slots = 2 * n_cus, bb = 128 / HW, sb = 96 / HW, nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
+                const int nwg = (n + bb - 1) / bb;
+                const bool mix = nb / slots + 0.78 * ((ns + slots - 1) / slots) < (double)((nwg + slots - 1) / slots);      // make_trunk_plan's choice
+                const double share = n > 0 && mix ? (nb * 128.0 * 30.0 / 36.0 + ns * 96.0 * 48.0 / 54.0) / ((double)n * HW) : 1.0;
+                char buf[640];
+                snprintf(buf, sizeof(buf), "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, "
+                         "implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS; the cells of each board edge form whole MFMA tiles that sit out "
+                         "the taps on which they read only zero padding: MFMA work issued = %.3f of the counted FLOPs)", share);
+                dom_label = buf;
+                if (mix) return dom_label.c_str();
+            }
             if (trunk_whole) return trunk_m16 ? "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS)"
                                               : "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, implicit GEMM on v_mfma_f32_32x32x16_bf16, activations resident in LDS)";
             return trunk_m16 ? "k_trunk (the whole residual trunk: blocks x two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS)"
@@ -1134,6 +1234,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
     hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
+    hipFuncSetAttribute((const void*)(k_trunk_mix<8, 2, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(128));
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 128, 2, 2, 2, 2, 2, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1159,7 +1260,7 @@ namespace gaz {
 
 typedef TeamGame<GAME_C4> GP4;
 
-template <bool MIX> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
     if ((int)blockIdx.x < n_tree_blocks) {
         // ---- tree role: wave w of the block steps games [(4 b + w) PER, +PER); its scratch lives in the launch's dynamic LDS
         constexpr int PER = WAVE / GP4::TEAM, NT = (TR_THREADS / WAVE) * PER;
@@ -1174,8 +1275,8 @@ template <bool MIX> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trun
     }
     // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid
     const int bid = (int)blockIdx.x - n_tree_blocks;
-    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows);
-    else trunk_tile<2, 2, 8, true, true, false, true>(a, (long)bid * a.tile_rows, a.tile_rows);
+    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, a.perm_small);
+    else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, a.perm);
 }
 
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {
@@ -1184,8 +1285,10 @@ bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1,
     const DevParams<GP4>& E = *static_cast<const DevParams<GP4>*>(dev_params);
     constexpr int GAMES_PER_BLOCK = (TR_THREADS / WAVE) * (WAVE / GP4::TEAM);
     const int n_tree = (g1 - g0 + GAMES_PER_BLOCK - 1) / GAMES_PER_BLOCK;
-    if (P.mix) hipLaunchKernelGGL(k_wave_trunk<true>, dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
-    else hipLaunchKernelGGL(k_wave_trunk<false>, dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    const bool skip = P.args.perm && P.args.perm_small;       // both tile shapes carry an edge-tile permutation (checked by the evaluator)
+    if (P.mix && skip) hipLaunchKernelGGL((k_wave_trunk<true, true>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    else if (P.mix) hipLaunchKernelGGL((k_wave_trunk<true, false>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    else hipLaunchKernelGGL((k_wave_trunk<false, false>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
     return true;
 }
 

@@ -39,6 +39,10 @@ struct TrunkArgs {
     // w then starts with block 0's 29 slices (conv1 channels 0-127 | 128-255, conv2, projection low | high); prm0 [1024] =
     // bn1 scale [256] | bn1 shift [256] | pad [128] | conv1 scale [128] | conv1 shift [128] | conv2 bias + projection bias [128]
     const bf16_t* x0; const float* prm0;
+    // 16x16x32 build: which image row (cell of the tile) each MFMA row of the workgroup computes — [MFMA row] -> image row, a bijection, or
+    // null = identity.  The host (tile_perm, resnet.hip) gathers the cells of a board edge into whole 16-row MFMA tiles: such a tile reads
+    // nothing but zero padding on the three taps that look across its edge, and the kernel skips its MFMAs there (see conv_taps).
+    const uint8_t* perm; const uint8_t* perm_small;     // tile_rows-shaped tiles; small_rows-shaped tiles (k_trunk_mix)
     // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
     const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
@@ -83,8 +87,8 @@ template <bool M16> __device__ __forceinline__ int swz_inv(int sp, int row) { re
 // re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
 // NW = waves per workgroup (4; 8 for the 256-row Gomoku tile: WM = 4 waves down the cells, one workgroup per CU with both images in LDS).
-template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false>
-__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows) {
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
+__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows, const uint8_t* perm = nullptr) {
     static_assert(!B0 || (M16 && !STEM && !HEADS && !RESG), "block 0 inside the launch: 16x16x32 build with both images in LDS");
     constexpr int SL0 = B0 ? 29 : 0;                // weight slices of block 0 ahead of the regular blocks' 18 each
     constexpr int BN = 128, SLOTS = 16, WM = NW / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS, THREADS = 64 * NW;
@@ -290,7 +294,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     int crow[NC]; unsigned cmask[NC];
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
-        crow[t] = wm * TM * 32 + t * 16 + l15;
+        const int mrow = wm * TM * 32 + t * 16 + l15;
+        crow[t] = perm ? (int)perm[mrow] : mrow;
         unsigned mm = 0;
         if (crow[t] < tile_rows && m0 + crow[t] < a.M) {
             const int cell = crow[t] % HW, y = cell / a.W, x = cell % a.W;
@@ -314,13 +319,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     const unsigned ldsb = (unsigned)(size_t)(lds_ptr_t)As;
     if (ldsb & 255u) __builtin_trap();
     int pb[NC], pbn[NC];                            // byte address of k-group lq of k-step 0 of this lane's operand row
-    auto tap_rows = [&](int tap, int (&o)[NC]) {
+    auto tap_rows = [&](int tap, int (&o)[NC], int zz = 0) {       // zz: an opaque 0 (conv_taps_static)
         const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
 #pragma unroll
         for (int t = 0; t < NC; ++t) {
             const bool ok = (cmask[t] >> tap) & 1u;
             const int ar = ok ? crow[t] + off : ZROW + ((crow[t] + off) & 15);
-            o[t] = (int)ldsb + ar * 256 + (swz_slot<true>(lq, ar) << 4);          // k-step ks: ^ (ks << 5), see below
+            o[t] = ((int)ldsb | zz) + ar * 256 + (swz_slot<true>(lq, ar) << 4);   // k-step ks: ^ (ks << 5), see below
         }
     };
     u32x4_t cfr[2][NC];                             // cell fragments, one k-step (256 MFMA cycles) ahead, across the tap boundary
@@ -365,6 +370,54 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                         acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
 #pragma unroll
                 for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);    // the next slice's k-step ks; the very last slice re-reads itself
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t) pb[t] = pbn[t];
+        }
+    };
+    // The same nine taps with the taps unrolled and, per tap, the MFMA tiles that sit it out known at compile time (M0 / M1: bit q = MFMA
+    // tile 0 / 1 of this wave reads only zero padding on tap q, see TrunkArgs::perm): straight-line code, no MFMAs and no fragment reads
+    // for a tile on the taps it sits out.  (Run-time branches around the MFMAs cost more than the skipped MFMAs give: 524 vs 490 us.)
+    auto conv_taps_static = [&](auto m0c, auto m1c, const int sl0) {
+        constexpr unsigned M0 = decltype(m0c)::value, M1 = decltype(m1c)::value;
+        // with the taps unrolled the nine sets of fragment addresses are invariants of the block loop, and hoisted out of it they cost 36
+        // registers the tap loop does not have (191 spilled): an opaque zero ties them to this call
+        int zz = 0;
+        asm volatile("" : "+v"(zz));
+        tap_rows(0, pb, zz);
+#pragma unroll
+        for (int t = 0; t < NC; ++t) cfr[0][t] = *(lds_u4_t)(unsigned)pb[t];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sl = sl0 + tap;
+            const int nsl = sl < last_slice ? sl + 1 : sl;
+            tap_rows(tap < 8 ? tap + 1 : 8, pbn, zz);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+#pragma unroll
+                for (int ct = 0; ct < NCH / 2; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)))
+                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const int ntap = ks + 1 < KS32 ? tap : (tap < 8 ? tap + 1 : 8);       // the tap the fragment is for
+                    if (!(t == 0 && ((M0 >> ntap) & 1u)) && !(t == 1 && ((M1 >> ntap) & 1u)))
+                        cfr[(ks + 1) & 1][t] = *(lds_u4_t)(unsigned)((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 5));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = NCH / 2; ct < NCH; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)))
+                            acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -435,6 +488,12 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         }
         __syncthreads();
     }
+    // The block loop, once per set of sit-out masks: a wave row with a row permutation runs the instance whose tap loop is straight-line code
+    // for ITS edge tiles (m0c / m1c: TrunkArgs::perm, conv_taps_static); 0 / 0 = the plain loop.  The instances are whole-wave alternatives
+    // (every wave of the workgroup passes the same barriers in the same order), so no branch sits inside a loop: two tap-loop variants in
+    // an if / else INSIDE the block loop cost 175 spilled registers.
+    auto block_loop = [&](auto m0c, auto m1c) {
+    constexpr bool STATIC_TAPS = decltype(m0c)::value != 0 || decltype(m1c)::value != 0;
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -445,7 +504,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
         for (int conv = 0; conv < 2; ++conv) {
             zero_acc16();
-            conv_taps(SL0 + blk * 18 + conv * 9, 0, 9);
+            if constexpr (STATIC_TAPS) conv_taps_static(m0c, m1c, SL0 + blk * 18 + conv * 9);
+            else conv_taps(SL0 + blk * 18 + conv * 9, 0, 9);
             if (blk < 10) TR_STAMP(3 + 6 * blk + 3 * conv);
             if (conv == 0) {
                 if (more && tid < TR_PRM / 4) Ps4[((blk + 1) & 1) * (TR_PRM / 4) + tid] = pnext;
@@ -494,6 +554,17 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         }
         __syncthreads();
         if (blk < 10) TR_STAMP(8 + 6 * blk);
+    }
+    };
+    typedef std::integral_constant<unsigned, 0u> no_mask;
+    if constexpr (SKIPSET == 1) {                   // two wave rows: (y = 0 edge, x = 0 edge) | (y = H - 1 edge, x = W - 1 edge)
+        if (wm == 0) block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x049u>{});
+        else block_loop(std::integral_constant<unsigned, 0x1C0u>{}, std::integral_constant<unsigned, 0x124u>{});
+    } else if constexpr (SKIPSET == 2) {              // one wave row: y = 0 edge, y = H - 1 edge
+        block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x1C0u>{});
+    } else {                                        // (a Gomoku board in 256 rows has one tile per edge = four wave-row roles: four instances
+                                                    // of this loop in one kernel spill 139 - 159 registers, measured 1458 vs 1840 positions/s: not built)
+        block_loop(no_mask{}, no_mask{});
     }
     } else {
 #pragma unroll 1
@@ -710,9 +781,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false>
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0, SKIPSET>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIPSET ? a.perm : nullptr);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
@@ -720,10 +791,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
 // the others.  Here the first n_big workgroups (whole rounds) take 3 boards in the 128-row shape and the rest 2 boards in a 96-row
 // shape (TM = 3, WN = 4: every wave all 96 cells x 32 channels) that issues three quarters of the MFMAs: 1024 + 512 tiles = three full
 // rounds, the last one cheaper.
-template <int RING, int OCC, bool STEM, bool HEADS, bool M16 = false>
+template <int RING, int OCC, bool STEM, bool HEADS, bool M16 = false, bool SKIP = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk_mix(TrunkArgs a) {
-    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows);
-    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows);
+    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 1 : 0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, a.perm);
+    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows, a.perm_small);
 }
 
 }  // namespace gaz

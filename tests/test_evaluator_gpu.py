@@ -104,6 +104,26 @@ def test_rows_are_batch_independent_generic_networks(game, blocks, filters, n):
     eng.close()
 
 
+@pytest.mark.parametrize("blocks,n", [(1, 1), (2, 2), (2, 7), (6, 100), (3, 1537), (6, 4096)])
+def test_edge_tile_permutation_is_bit_identical(blocks, n, monkeypatch):
+    """trunk.hpp / TrunkArgs::perm: the cells of each board edge gathered into whole 16-row MFMA tiles that sit out the taps on which
+    they read nothing but zero padding (30 of 36 tile-taps per wave left on a 3-board tile, 48 of 54 on a 2-board tile).  The skipped
+    products are exact zeros, so policy, value and head features equal the natural row order (GAZ_TILE_PERM=0) bit for bit — ragged
+    batches (last tile with 1 or 2 boards, 2-board tiles of the mixed launch) included."""
+    rng = np.random.default_rng(blocks * 1000 + n)
+    x = _random_states(n, rng)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GAZ_TILE_PERM", flag)
+        net, eng = _mk(max(n, 8), blocks, True, seed=3)
+        p, v, _ = eng.evaluate(x)
+        pf, vf = eng.head_features(n)
+        outs.append((p, v, pf.copy(), vf.copy()))
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("blocks,n", [(1, 5), (6, 334), (3, 4096)])
 def test_whole_trunk_kernel_equals_per_block_kernels(blocks, n, monkeypatch):
     """k_trunk / k_trunk_mix (csrc/trunk.hpp: stem, every residual block and the heads' first convolution in one launch, activations
