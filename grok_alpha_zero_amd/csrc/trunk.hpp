@@ -715,8 +715,14 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         // 32-channel MFMA tile) + each head's flat BN + ReLU, as k_conv_heads computes them, from the raw x image: wave w takes cells
         // [32 w, 32 w + 32) x the 32 channels.  72 MFMAs per wave with one MFMA per k-step, so the weight ring is three taps deep.
         constexpr int HBSL = 32 * SLOTS, HRING = 24;
+        // the lane geometry of this phase is recomputed from an opaque copy of the thread index: taken from the values set up before the
+        // block loop it stays live across the loop, which the static tap loops cannot afford (11 spilled registers, 40 MB of scratch traffic
+        // per launch)
+        int tidh = tid;
+        asm volatile("" : "+v"(tidh));
+        const int l31h = tidh & 31, lhih = (tidh >> 5) & 1, waveh = tidh >> 6;
         const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.hw, 0, 9 * HBSL * 16, 0x00020000);
-        const int hvo = (lhi * 32 + l31) * 16;
+        const int hvo = (lhih * 32 + l31h) * 16;
         auto ldh = [&](int tap, int ks) -> uint4 {
             const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(hrs, hvo, (tap * HBSL + ks * 2 * 32) * 16, 0);
             return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
@@ -724,11 +730,17 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         uint4 hfr[HRING];
 #pragma unroll
         for (int g = 0; g < HRING; ++g) hfr[g] = ldh(g / KS, g % KS);
-        const int htile = WN == 2 ? wn : wave;      // which of this wave's own cell tiles is cell tile `wave` of the workgroup
-        int hrow = lrow[0]; unsigned hmask = vmask[0];
+        const int hrow = waveh * 32 + l31h;         // cell tile `wave` of the workgroup
+        unsigned hmask = 0;
+        if (hrow < tile_rows && m0 + hrow < a.M) {
+            const int cell = hrow % HW, y = cell / a.W, x = cell % a.W;
 #pragma unroll
-        for (int tm = 1; tm < TM; ++tm) if (htile == tm) { hrow = lrow[tm]; hmask = vmask[tm]; }
-        if (htile < TM) {                           // wave-uniform (WN = 4, TM = 3: the fourth wave has no cell tile)
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                hmask |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
+            }
+        }
+        if (waveh * 32 < ROWS) {                    // wave-uniform (WN = 4, TM = 3: the fourth wave has no cell tile)
         f32x16 hacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
@@ -740,7 +752,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 const bool ok = (hmask >> tap) & 1u;
                 const int ar = hrow + off;
                 // k-group 2 ks + lhi of row ar: 32x32x16 layout slot (lhi ^ ar & 15) ^ 2 ks; 16x16x32 layout slot (lhi << 3 | ar & 7) ^ ks
-                const int pbh = (ok ? ROWS + TR_ZROWS + ar : ZROW + (ar & 15)) * 256 + (swz_slot<M16>(lhi, ar) << 4);
+                const int pbh = (ok ? ROWS + TR_ZROWS + ar : ZROW + (ar & 15)) * 256 + (swz_slot<M16>(lhih, ar) << 4);
                 uint4 hf[KS];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) hf[ks] = *reinterpret_cast<const uint4*>(Ab + (pbh ^ (ks * (M16 ? 16 : 32))));
@@ -756,10 +768,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         const long gr = m0 + hrow;
         if (hrow < tile_rows && gr < a.M) {
             const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = (int)((unsigned)gr - b * (unsigned)HW);
-            const int f = cell * 8 + 4 * lhi;
+            const int f = cell * 8 + 4 * lhih;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float4 bi = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhi);
+                const float4 bi = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhih);
                 const float4 sc = *reinterpret_cast<const float4*>((j ? a.v_fs : a.p_fs) + f);
                 const float4 sh = *reinterpret_cast<const float4*>((j ? a.v_ft : a.p_ft) + f);
                 float4 o;
