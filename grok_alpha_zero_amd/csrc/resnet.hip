@@ -467,7 +467,8 @@ __global__ __launch_bounds__(128) void k_tail(TailArgs a) {
 // over the waves; leftover padding rows make all-padding tiles (they sit out every tap); every other cell keeps its natural order.  Inside
 // a tile the rows are ordered so that the two groups of eight lanes a ds_read_b128 serves together ({0-3, 12-15} and {4-11}) hit eight
 // different row & 7 (the image swizzle's conflict-free condition).  Connect4, three boards in 128 rows: four edge tiles, 30 of 36 tile-taps
-// per wave left (-16.7 % MFMAs); two boards in 96 rows: two edge tiles (-11 %); a Gomoku board in 256 rows: four edge tiles (-8.3 %).
+// per wave left (-16.7 % MFMAs); two boards in 96 rows: two edge tiles (-11 %).  (A Gomoku board in 256 rows would give four edge tiles, one per
+// wave row, -8.3 %: that is four instances of the kernel's block loop, which spill — see trunk.hpp — so the Gomoku launch keeps the natural order.)
 static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wave_rows) {
     const int HW = H * W, cells = boards * HW, n_wr = rows / wave_rows, max_special = 2 * n_wr;
     std::vector<uint8_t> none;
@@ -477,14 +478,27 @@ static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wa
     for (int r = rows - 1; r >= cells; --r) pads.push_back(r);      // taken from the back: lowest padding row first
     auto edges_of = [&](int c) { const int cell = c % HW, y = cell / W, x = cell % W; return (y == 0) + (y == H - 1) + (x == 0) + (x == W - 1); };
     auto in_group = [&](int c, int g) { const int cell = c % HW, y = cell / W, x = cell % W; return g == 0 ? y == 0 : g == 1 ? y == H - 1 : g == 2 ? x == 0 : x == W - 1; };
+    // a tile reads without LDS bank conflicts when each of its two groups of eight lanes sees eight different row & 7, i.e. when it holds at
+    // most two rows of every residue: pick with that in mind (every residue has rows / 8 rows, so a perfect split exists for the whole tile)
     std::vector<std::vector<int>> special;
+    auto pick16 = [&](const std::vector<int>& cand, std::vector<int>& t) {       // up to 16 - t.size() more rows from cand, at most two per residue first
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r : t) cnt[r & 7]++;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c : cand) {
+                if ((int)t.size() >= 16) return;
+                if (std::find(t.begin(), t.end(), c) != t.end() || used[c]) continue;
+                if (pass == 0 && cnt[c & 7] >= 2) continue;
+                t.push_back(c); cnt[c & 7]++;
+            }
+    };
     for (int g = 0; g < 4 && (int)special.size() < max_special; ++g) {
         std::vector<int> avail;
         for (int pass = 1; pass <= 2; ++pass)                       // cells of this edge only first, corners (shared with another edge) last
             for (int c = 0; c < cells; ++c) if (!used[c] && in_group(c, g) && (edges_of(c) == 1) == (pass == 1)) avail.push_back(c);
-        const int take = std::min<int>(16, (int)avail.size());
-        if (take == 0 || 16 - take > (int)pads.size()) continue;
-        std::vector<int> t(avail.begin(), avail.begin() + take);
+        if (avail.empty() || 16 - std::min<int>(16, (int)avail.size()) > (int)pads.size()) continue;
+        std::vector<int> t;
+        pick16(avail, t);
         while ((int)t.size() < 16) { t.push_back(pads.back()); pads.pop_back(); }
         for (int r : t) used[r] = 1;
         special.push_back(t);
@@ -495,13 +509,16 @@ static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wa
         for (int r : t) used[r] = 1;
         special.push_back(t);
     }
-    // special tile k -> wave-row k % n_wr, MFMA tile k / n_wr of it; the other tiles take the remaining rows in natural order
+    // special tile k -> wave-row k % n_wr, MFMA tile k / n_wr of it; the other tiles share out the remaining rows, two per residue each
     std::vector<std::vector<int>> tiles(rows / 16);
-    for (size_t k = 0; k < special.size(); ++k) tiles[(k % n_wr) * (wave_rows / 16) + k / n_wr] = special[k];
-    int next = 0;
-    for (auto& t : tiles) {
-        if (!t.empty()) continue;
-        while ((int)t.size() < 16) { while (used[next]) ++next; t.push_back(next); used[next] = 1; }
+    std::vector<char> is_special(rows / 16, 0);
+    for (size_t k = 0; k < special.size(); ++k) { const size_t ti = (k % n_wr) * (wave_rows / 16) + k / n_wr; tiles[ti] = special[k]; is_special[ti] = 1; }
+    std::vector<int> rest;
+    for (int r = 0; r < rows; ++r) if (!used[r]) rest.push_back(r);
+    for (size_t ti = 0; ti < tiles.size(); ++ti) {
+        if (is_special[ti]) continue;
+        pick16(rest, tiles[ti]);
+        for (int r : tiles[ti]) used[r] = 1;
     }
     std::vector<uint8_t> perm(rows);
     const int P1[8] = {0, 1, 2, 3, 12, 13, 14, 15}, P2[8] = {4, 5, 6, 7, 8, 9, 10, 11};
