@@ -461,7 +461,7 @@ __global__ __launch_bounds__(128) void k_tail(TailArgs a) {
 }
 
 // [MFMA row of a workgroup's tile] -> image row (cell of the tile; rows >= boards * H * W are padding), for TrunkArgs::perm.  The tile is
-// `rows` MFMA rows = rows / 16 MFMA tiles; a wave computes `wave_rows` consecutive MFMA rows, and the kernel can let a wave's FIRST TWO MFMA
+// `rows` MFMA rows = rows / 16 MFMA tiles; a wave computes `wave_rows` consecutive MFMA rows, and the kernel can let a wave's FIRST `per_wave_row` MFMA
 // tiles sit out a tap when all 16 of their cells read zero padding there.  So: the cells of each board edge (y = 0, y = H - 1, x = 0,
 // x = W - 1; topped up with padding rows) become whole MFMA tiles — each sits out the three taps that look across its edge — dealt out
 // over the waves; leftover padding rows make all-padding tiles (they sit out every tap); every other cell keeps its natural order.  Inside
@@ -469,8 +469,8 @@ __global__ __launch_bounds__(128) void k_tail(TailArgs a) {
 // different row & 7 (the image swizzle's conflict-free condition).  Connect4, three boards in 128 rows: four edge tiles, 30 of 36 tile-taps
 // per wave left (-16.7 % MFMAs); two boards in 96 rows: two edge tiles (-11 %).  (A Gomoku board in 256 rows would give four edge tiles, one per
 // wave row, -8.3 %: that is four instances of the kernel's block loop, which spill — see trunk.hpp — so the Gomoku launch keeps the natural order.)
-static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wave_rows) {
-    const int HW = H * W, cells = boards * HW, n_wr = rows / wave_rows, max_special = 2 * n_wr;
+static std::vector<uint8_t> tile_perm(int H, int W, int boards, int rows, int wave_rows, int per_wave_row = 2) {
+    const int HW = H * W, cells = boards * HW, n_wr = rows / wave_rows, max_special = per_wave_row * n_wr;
     std::vector<uint8_t> none;
     if (rows > 256 || rows % 16 || wave_rows % 16 || rows % wave_rows || cells > rows || wave_rows < 32) return none;
     std::vector<char> used(rows, 0);
@@ -628,12 +628,12 @@ struct ResNetEvaluator : Evaluator {
         }
         if (!(getenv("GAZ_TILE_PERM") && atoi(getenv("GAZ_TILE_PERM")) == 0) && !perm_big && 96 / HW >= 1) {
             // the kernels' static sit-out masks (trunk.hpp conv9): 128-row tile = two wave rows (y = 0 | x = 0) and (y = H - 1 | x = W - 1); 96-row
-            // tile = one wave row (y = 0 | y = H - 1).  Both permutations must deliver exactly that, or neither is used.
-            const std::vector<uint8_t> pb = tile_perm(H, W, 128 / HW, 128, 64), ps = tile_perm(H, W, 96 / HW, 96, 96);
-            const unsigned want_big[4] = {0x007u, 0x049u, 0x1C0u, 0x124u}, want_small[2] = {0x007u, 0x1C0u};
+            // tile = one wave row (y = 0 | y = H - 1 | x = 0).  Both permutations must deliver exactly that, or neither is used.
+            const std::vector<uint8_t> pb = tile_perm(H, W, 128 / HW, 128, 64), ps = tile_perm(H, W, 96 / HW, 96, 96, 3);
+            const unsigned want_big[4] = {0x007u, 0x049u, 0x1C0u, 0x124u}, want_small[3] = {0x007u, 0x1C0u, 0x049u};
             bool ok = !pb.empty() && !ps.empty();
             for (int wr = 0; ok && wr < 2; ++wr) for (int t = 0; t < 2; ++t) ok = ok && (tile_sitout(pb, H, W, 128 / HW, wr * 4 + t) & want_big[wr * 2 + t]) == want_big[wr * 2 + t];
-            for (int t = 0; ok && t < 2; ++t) ok = (tile_sitout(ps, H, W, 96 / HW, t) & want_small[t]) == want_small[t];
+            for (int t = 0; ok && t < 3; ++t) ok = (tile_sitout(ps, H, W, 96 / HW, t) & want_small[t]) == want_small[t];
             if (ok && (perm_big = dalloc<uint8_t>(pb.size())) && (perm_small = dalloc<uint8_t>(ps.size()))) {
                 hipMemcpy(perm_big, pb.data(), pb.size(), hipMemcpyHostToDevice); hipMemcpy(perm_small, ps.data(), ps.size(), hipMemcpyHostToDevice);
             } else { perm_big = perm_small = nullptr; }
@@ -830,11 +830,11 @@ struct ResNetEvaluator : Evaluator {
         if (fused && trunk) {
             *flops = 2 * conv * blocks;
             if (trunk_whole && trunk_m16 && trunk_mix && perm_big && perm_small) {
-                // MFMA rows x taps actually issued / counted (n HW rows x 9 taps): 128-row tiles run 30 of 36 tile-taps per wave, 96-row tiles 48 of 54
+                // MFMA rows x taps actually issued / counted (n HW rows x 9 taps): 128-row tiles run 30 of 36 tile-taps per wave, 96-row tiles 45 of 54
                 const int slots = 2 * n_cus, bb = 128 / HW, sb = 96 / HW, nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
                 const int nwg = (n + bb - 1) / bb;
                 const bool mix = nb / slots + 0.78 * ((ns + slots - 1) / slots) < (double)((nwg + slots - 1) / slots);      // make_trunk_plan's choice
-                const double share = n > 0 && mix ? (nb * 128.0 * 30.0 / 36.0 + ns * 96.0 * 48.0 / 54.0) / ((double)n * HW) : 1.0;
+                const double share = n > 0 && mix ? (nb * 128.0 * 30.0 / 36.0 + ns * 96.0 * 45.0 / 54.0) / ((double)n * HW) : 1.0;
                 char buf[640];
                 snprintf(buf, sizeof(buf), "k_trunk_mix (stem + the whole residual trunk + heads' first conv in one launch: blocks x two 3x3 convs 128->128 counted, "
                          "implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS; the cells of each board edge form whole MFMA tiles that sit out "

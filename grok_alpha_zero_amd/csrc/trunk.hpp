@@ -379,8 +379,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     // The same nine taps with the taps unrolled and, per tap, the MFMA tiles that sit it out known at compile time (M0 / M1: bit q = MFMA
     // tile 0 / 1 of this wave reads only zero padding on tap q, see TrunkArgs::perm): straight-line code, no MFMAs and no fragment reads
     // for a tile on the taps it sits out.  (Run-time branches around the MFMAs cost more than the skipped MFMAs give: 524 vs 490 us.)
-    auto conv_taps_static = [&](auto m0c, auto m1c, const int sl0) {
-        constexpr unsigned M0 = decltype(m0c)::value, M1 = decltype(m1c)::value;
+    auto conv_taps_static = [&](auto m0c, auto m1c, auto m2c, const int sl0) {
+        constexpr unsigned M0 = decltype(m0c)::value, M1 = decltype(m1c)::value, M2 = decltype(m2c)::value;
         // with the taps unrolled the nine sets of fragment addresses are invariants of the block loop, and hoisted out of it they cost 36
         // registers the tap loop does not have (191 spilled): an opaque zero ties them to this call
         int zz = 0;
@@ -400,13 +400,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 for (int ct = 0; ct < NCH / 2; ++ct)
 #pragma unroll
                     for (int t = 0; t < NC; ++t)
-                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)))
+                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)) && !(t == 2 && ((M2 >> tap) & 1u)))
                             acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NC; ++t) {
                     const int ntap = ks + 1 < KS32 ? tap : (tap < 8 ? tap + 1 : 8);       // the tap the fragment is for
-                    if (!(t == 0 && ((M0 >> ntap) & 1u)) && !(t == 1 && ((M1 >> ntap) & 1u)))
+                    if (!(t == 0 && ((M0 >> ntap) & 1u)) && !(t == 1 && ((M1 >> ntap) & 1u)) && !(t == 2 && ((M2 >> ntap) & 1u)))
                         cfr[(ks + 1) & 1][t] = *(lds_u4_t)(unsigned)((ks + 1 < KS32 ? pb[t] : pbn[t]) ^ (((ks + 1) % KS32) << 5));
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -414,7 +414,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 for (int ct = NCH / 2; ct < NCH; ++ct)
 #pragma unroll
                     for (int t = 0; t < NC; ++t)
-                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)))
+                        if (!(t == 0 && ((M0 >> tap) & 1u)) && !(t == 1 && ((M1 >> tap) & 1u)) && !(t == 2 && ((M2 >> tap) & 1u)))
                             acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
 #pragma unroll
                 for (int ct = 0; ct < NCH; ++ct) wfr[ks][ct] = ldw(nsl, ks, ct);
@@ -492,8 +492,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     // for ITS edge tiles (m0c / m1c: TrunkArgs::perm, conv_taps_static); 0 / 0 = the plain loop.  The instances are whole-wave alternatives
     // (every wave of the workgroup passes the same barriers in the same order), so no branch sits inside a loop: two tap-loop variants in
     // an if / else INSIDE the block loop cost 175 spilled registers.
-    auto block_loop = [&](auto m0c, auto m1c) {
-    constexpr bool STATIC_TAPS = decltype(m0c)::value != 0 || decltype(m1c)::value != 0;
+    auto block_loop = [&](auto m0c, auto m1c, auto m2c) {
+    constexpr bool STATIC_TAPS = decltype(m0c)::value != 0 || decltype(m1c)::value != 0 || decltype(m2c)::value != 0;
 #pragma unroll 1
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const float* P = Ps + (blk & 1) * TR_PRM;
@@ -504,7 +504,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
         for (int conv = 0; conv < 2; ++conv) {
             zero_acc16();
-            if constexpr (STATIC_TAPS) conv_taps_static(m0c, m1c, SL0 + blk * 18 + conv * 9);
+            if constexpr (STATIC_TAPS) conv_taps_static(m0c, m1c, m2c, SL0 + blk * 18 + conv * 9);
             else conv_taps(SL0 + blk * 18 + conv * 9, 0, 9);
             if (blk < 10) TR_STAMP(3 + 6 * blk + 3 * conv);
             if (conv == 0) {
@@ -558,13 +558,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     };
     typedef std::integral_constant<unsigned, 0u> no_mask;
     if constexpr (SKIPSET == 1) {                   // two wave rows: (y = 0 edge, x = 0 edge) | (y = H - 1 edge, x = W - 1 edge)
-        if (wm == 0) block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x049u>{});
-        else block_loop(std::integral_constant<unsigned, 0x1C0u>{}, std::integral_constant<unsigned, 0x124u>{});
-    } else if constexpr (SKIPSET == 2) {              // one wave row: y = 0 edge, y = H - 1 edge
-        block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x1C0u>{});
+        if (wm == 0) block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x049u>{}, no_mask{});
+        else block_loop(std::integral_constant<unsigned, 0x1C0u>{}, std::integral_constant<unsigned, 0x124u>{}, no_mask{});
+    } else if constexpr (SKIPSET == 2) {              // one wave row: y = 0 edge, y = H - 1 edge, x = 0 edge (the padding rows fill it up)
+        block_loop(std::integral_constant<unsigned, 0x007u>{}, std::integral_constant<unsigned, 0x1C0u>{}, std::integral_constant<unsigned, 0x049u>{});
     } else {                                        // (a Gomoku board in 256 rows has one tile per edge = four wave-row roles: four instances
                                                     // of this loop in one kernel spill 139 - 159 registers, measured 1458 vs 1840 positions/s: not built)
-        block_loop(no_mask{}, no_mask{});
+        block_loop(no_mask{}, no_mask{}, no_mask{});
     }
     } else {
 #pragma unroll 1

@@ -107,7 +107,7 @@ def test_rows_are_batch_independent_generic_networks(game, blocks, filters, n):
 @pytest.mark.parametrize("blocks,n", [(1, 1), (2, 2), (2, 7), (6, 100), (3, 1537), (6, 4096)])
 def test_edge_tile_permutation_is_bit_identical(blocks, n, monkeypatch):
     """trunk.hpp / TrunkArgs::perm: the cells of each board edge gathered into whole 16-row MFMA tiles that sit out the taps on which
-    they read nothing but zero padding (30 of 36 tile-taps per wave left on a 3-board tile, 48 of 54 on a 2-board tile).  The skipped
+    they read nothing but zero padding (30 of 36 tile-taps per wave left on a 3-board tile, 45 of 54 on a 2-board tile).  The skipped
     products are exact zeros, so policy, value and head features equal the natural row order (GAZ_TILE_PERM=0) bit for bit — ragged
     batches (last tile with 1 or 2 boards, 2-board tiles of the mixed launch) included."""
     rng = np.random.default_rng(blocks * 1000 + n)
