@@ -41,7 +41,8 @@ struct TrunkArgs {
     const bf16_t* x0; const float* prm0;
     // 16x16x32 build: which image row (cell of the tile) each MFMA row of the workgroup computes — [MFMA row] -> image row, a bijection, or
     // null = identity.  The host (tile_perm, resnet.hip) gathers the cells of a board edge into whole 16-row MFMA tiles: such a tile reads
-    // nothing but zero padding on the three taps that look across its edge, and the kernel skips its MFMAs there (see conv_taps).
+    // nothing but zero padding on the three taps that look across its edge, and the kernel variants built with SKIPSET != 0 leave its MFMAs
+    // out there (conv_taps_static; the host launches them only with permutations that deliver exactly the masks they assume).
     const uint8_t* perm; const uint8_t* perm_small;     // tile_rows-shaped tiles; small_rows-shaped tiles (k_trunk_mix)
     // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
     const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
