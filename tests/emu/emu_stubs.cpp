@@ -8,3 +8,13 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config&, int, int, int, int, s
 }
 bool launch_wave_trunk_c4(hipStream_t, const void*, int, int, const void*) { return false; }
 }
+
+// test hook (tests/test_tile_perm.py): the host-side tile permutation of the trunk kernel's edge tiles
+#include "../../grok_alpha_zero_amd/csrc/tile_perm.hpp"
+extern "C" int gaz_test_tile_perm(int H, int W, int boards, int rows, int wave_rows, int per_wave_row, uint8_t* perm_out, unsigned* sitout_out) {
+    const std::vector<uint8_t> p = gaz::tile_perm(H, W, boards, rows, wave_rows, per_wave_row);
+    if (p.empty()) return 0;
+    for (size_t i = 0; i < p.size(); ++i) perm_out[i] = p[i];
+    for (int t = 0; t < rows / 16; ++t) sitout_out[t] = gaz::tile_sitout(p, H, W, boards, t);
+    return (int)p.size();
+}
