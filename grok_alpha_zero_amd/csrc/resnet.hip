@@ -1204,8 +1204,8 @@ template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void 
     }
     // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid
     const int bid = (int)blockIdx.x - n_tree_blocks;
-    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, a.perm_small);
-    else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, a.perm);
+    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr);
+    else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr);
 }
 
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {

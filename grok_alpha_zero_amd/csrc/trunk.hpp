@@ -806,8 +806,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
 // rounds, the last one cheaper.
 template <int RING, int OCC, bool STEM, bool HEADS, bool M16 = false, bool SKIP = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk_mix(TrunkArgs a) {
-    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 1 : 0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, a.perm);
-    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows, a.perm_small);
+    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 1 : 0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr);
+    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr);
 }
 
 }  // namespace gaz
