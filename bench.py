@@ -47,6 +47,9 @@ def parse(argv=None):
     ap.add_argument("--cache-leg", type=int, default=-1, help="log2 entries of the evaluation cache used by the extra with_eval_cache leg (0 = skip the leg; default 24, Gomoku 0: 5 %% hits there)")
     ap.add_argument("--eval-cache", type=int, default=0, help="log2 entries of the on-device evaluation cache (SURVEY 8f rank 3); 0 = off (the headline number is measured with it off: every request goes through the evaluator)")
     ap.add_argument("--ref-convention-leg", type=int, default=-1, help="1: extra leg at int(1.5 * sims) simulations per move, what Self_Play passes for MCTS_iteration_limit = sims (Self_Play.py:99); default on for the connect4 config at N = 1")
+    ap.add_argument("--other-configs", type=int, default=-1, help="1: also measure BASELINE configs[4] (Gumbel) and configs[3] (Gomoku) and append them to the line as "
+                                                                  "'gumbel' / 'gomoku' objects (default: on for the plain headline command at N = 1)")
+    ap.add_argument("--stagger", type=int, default=1, help="1 (default): every slot's first game starts at a random ply (steady state from the first timed wave); 0: all at ply 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-baseline-cores", type=int, default=0, help="worker threads = torch threads of the CPU baseline (0 = the cores this "
@@ -227,15 +230,39 @@ CONFIGS = {   # game, games/GPU, sims/move, blocks, max_actions, explore first/s
 }
 
 
+# bytes one simulation moves through the tree kernel, SURVEY 8d: select d (12 A + 20) + backup 24 d + board 2 HW + new node 16 A' + 16 + bf16
+# network input 2 HW C + outputs 4 (A_all + 1), at (A, d, HW, C) = (7, 8, 42, 4) for Connect4 and (200, 4, 225, 2) for Gomoku
+TREE_BYTES_PER_SIM = {"Connect4": 8 * (12 * 7 + 20) + 24 * 8 + 2 * 42 + (16 * 7 + 16) + 42 * 4 * 2 + 4 * 8,
+                      "Gomoku": 4 * (12 * 200 + 20) + 24 * 4 + 2 * 225 + (16 * 200 + 16) + 225 * 2 * 2 + 4 * 226}
+
+
+def random_histories(game, n, rng, max_ply):
+    """n random legal NON-TERMINAL action histories (engine action indices) of 0 .. max_ply plies: where bench.py puts the slots before
+    the warm-up, so that the games are out of step from the start (a steady-state number) instead of all at ply 0."""
+    from grok_alpha_zero_amd.games import GAMES
+    cls = GAMES[game]
+    out = []
+    for _ in range(n):
+        want = int(rng.integers(0, max_ply + 1))
+        while True:
+            g = cls(); hist = []
+            for _ply in range(want):
+                legal = g.get_legal_actions()
+                a = legal[int(rng.integers(0, len(legal)))]
+                g.do_action(a); hist.append(cls.action_to_index(a))
+                if g.check_win() != -2:
+                    break
+            if g.check_win() == -2:
+                break
+        out.append(hist)
+    return out
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch(args, argv))
-    game, dG, dS, dB, max_actions, ef, es, cpuct, alpha, search, gm = CONFIGS[args.config]
-    args.games = args.games or dG; args.sims = args.sims or dS; args.blocks = args.blocks or dB
-    if args.cache_leg < 0:
-        args.cache_leg = 0 if args.config == "gomoku" else 24
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,168 +283,232 @@ def main():
     from grok_alpha_zero_amd.net import NETS, flops_per_position
     from grok_alpha_zero_amd.parallel import reduce_stats
 
-    G = args.games
-    gumbel = search == "gumbel"
-    use_net = args.evaluator == "resnet"
-    net = NETS[game](args.blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval() if (use_net or not args.no_cpu_baseline) else None
-    weights = net.export_engine_weights() if use_net else None
-
-    def make_engine(sims, cache_log2):
-        e = SelfPlayEngine(game, G, sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=0 if emu else local,
-                           evaluator=EVAL_RESNET if use_net else EVAL_HASH, net_blocks=args.blocks if use_net else 0,
-                           hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
-                           c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims,
-                           eval_cache_log2=cache_log2, lib_path=args.emu_lib or None)
-        if use_net:
-            e.load_weights(weights)
-        return e
-
-    def barrier(e):
-        e.synchronize()
-        if not emu:
-            torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    def max_over_ranks(dt):
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item())
-        return dt
-
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    def timed_run(e, with_timing):
-        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; -> (seconds (max over ranks), counter deltas)"""
-        for i in range(args.warmup):
-            e.run_waves(args.waves_per_step); e.synchronize()
-        barrier(e)
-        s0 = e.stats()
-        if with_timing:
-            e.timing_reset(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            e.run_waves(args.waves_per_step)
-        barrier(e)
-        dt = time.perf_counter() - t0
-        s1 = e.stats()
-        d = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]), s1["evals"] - s0["evals"],
-                      s1["sims"] - s0["sims"], s1["cache_hits"] - s0["cache_hits"]], np.int64)
-        return max_over_ranks(dt), d
+    def measure(config, G, sims_arg, blocks_arg, steps, warmup, legs):
+        """One configuration, start to finish -> (the result dict on rank 0 / None elsewhere, the network)."""
+        game, dG, dS, dB, max_actions, ef, es, cpuct, alpha, search, gm = CONFIGS[config]
+        G = G or dG; sims = sims_arg or dS; blocks = blocks_arg or dB
+        gumbel = search == "gumbel"
+        use_net = args.evaluator == "resnet"
+        net = NETS[game](blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval() if (use_net or not args.no_cpu_baseline) else None
+        weights = net.export_engine_weights() if use_net else None
+        cache_leg = args.cache_leg if args.cache_leg >= 0 else (0 if config == "gomoku" else 24)
 
-    eng = make_engine(args.sims, args.eval_cache)
-    log(f"engine ready: {world} rank(s) x {G} games, {args.sims} sims/move, evaluator={args.evaluator}")
-    dt, delta = timed_run(eng, True)
-    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
-    tm = eng.timing()
-    kname, kflops = eng.dominant_kernel()
-    fused = bool(eng.stats().get("fused_wave"))
-    tm_fused = None
-    if fused and use_net:
-        # The headline segment ran the tree step and the trunk kernel as ONE launch (k_wave_trunk): its duration includes the part of
-        # the tree step it could not hide, so it does not price the MFMA kernel.  Time the trunk kernel on its own in a second
-        # segment of this run: same engine, same games, tree step and trunk launched separately (results are bit-identical).
-        tm_fused, kname_fused = tm, kname
-        eng.set_fused_wave(False)
-        eng.timing_reset(True)
-        eng.run_waves(args.waves_per_step); eng.synchronize()
+        def make_engine(n_sims, cache_log2):
+            e = SelfPlayEngine(game, G, n_sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=0 if emu else local,
+                               evaluator=EVAL_RESNET if use_net else EVAL_HASH, net_blocks=blocks if use_net else 0,
+                               hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
+                               c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims,
+                               eval_cache_log2=cache_log2, lib_path=args.emu_lib or None)
+            if use_net:
+                e.load_weights(weights)
+            if args.stagger:
+                # steady state from the first timed wave (SURVEY 8d; VERDICT r2 weak 8): every slot starts its first game at a random ply of a
+                # random legal playout — the same positions on every run (seeded by the global slot) — instead of all 4096 at ply 0 in lockstep
+                span = {"Connect4": 24, "Gomoku": 60}.get(game, 4)
+                hs = random_histories(game, G, np.random.default_rng(977 + rank), span)
+                for slot, h in enumerate(hs):
+                    if h:
+                        e.set_position(slot, h)
+                e.synchronize()
+            return e
+
+        def barrier(e):
+            e.synchronize()
+            if not emu:
+                torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        def max_over_ranks(dt):
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item())
+            return dt
+
+        def timed_run(e, with_timing):
+            """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; -> (seconds (max over ranks), counter deltas)"""
+            for i in range(warmup):
+                e.run_waves(args.waves_per_step); e.synchronize()
+            barrier(e)
+            s0 = e.stats()
+            if with_timing:
+                e.timing_reset(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e.run_waves(args.waves_per_step)
+            barrier(e)
+            dt = time.perf_counter() - t0
+            s1 = e.stats()
+            d = np.array([int(s1["plies"] - s0["plies"]), int(s1["game_stats"][2] - s0["game_stats"][2]), s1["evals"] - s0["evals"],
+                          s1["sims"] - s0["sims"], s1["cache_hits"] - s0["cache_hits"], s1["fused_faults"]], np.int64)
+            return max_over_ranks(dt), d
+
+        eng = make_engine(sims, args.eval_cache)
+        log(f"[{config}] engine ready: {world} rank(s) x {G} games, {sims} sims/move, evaluator={args.evaluator}")
+        dt, delta = timed_run(eng, True)
+        log(f"[{config}] timed region done: {dt:.3f}s for {steps} steps")
         tm = eng.timing()
         kname, kflops = eng.dominant_kernel()
-        eng.set_fused_wave(True)
-    eng.timing_reset(False)
-    total = reduce_stats(delta, world)                      # the one collective of the path: counters only
-    positions, games, evals, sims, hits = (int(x) for x in total)
-    per_rank = np.zeros(world, np.int64); per_rank[rank] = delta[0]
-    per_rank = reduce_stats(per_rank, world)
-    eng.close()
+        fused = bool(eng.stats().get("fused_wave"))
+        tm_fused, kname_fused = None, None
+        if fused and use_net:
+            # The headline segment ran the tree step and the trunk kernel as ONE launch (k_wave_trunk): its duration includes the part of
+            # the tree step it could not hide, so it does not price the MFMA kernel.  Time the trunk kernel on its own in a second
+            # segment of this run: same engine, same games, tree step and trunk launched separately (results are bit-identical).
+            tm_fused, kname_fused = tm, kname
+            eng.set_fused_wave(False)
+            eng.timing_reset(True)
+            eng.run_waves(args.waves_per_step); eng.synchronize()
+            tm = eng.timing()
+            kname, kflops = eng.dominant_kernel()
+            eng.set_fused_wave(True)
+        eng.timing_reset(False)
+        t_red = time.perf_counter()
+        total = reduce_stats(delta[:5], world)                  # the one collective of the path: counters only
+        t_red = time.perf_counter() - t_red
+        positions, games, evals, n_sims, hits = (int(x) for x in total)
+        per_rank = np.zeros(world, np.int64); per_rank[rank] = delta[0]
+        per_rank = reduce_stats(per_rank, world)
+        faults = int(reduce_stats(delta[5:6], world)[0])
+        eng.close()
 
-    out = None
-    if rank == 0:
-        HWc = net.H * net.W if net is not None else 0
-        fl = (flops_per_position(args.blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * args.blocks)) if net is not None else dict(total=0.0)
-        roof = None
-        if use_net and tm["n_dominant"] > 0 and kflops > 0:
-            avg_ms = tm["ms_dominant"] / tm["n_dominant"]
-            ach = kflops / (avg_ms * 1e-3) / 1e12
-            traffic, traffic_src = None, None
-            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this very command
-            # (tools/profile_round.sh -> tools/pmc_traffic.py); a PMC pass cannot run inside the timed process, so the figure is
-            # profile-derived and labelled as such.  Only quoted for the workload it was collected on.
-            import glob
-            for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
-                tj = json.load(open(tf))
-                if args.config == "connect4" and G == 4096 and tj.get("kernel_tag") and kname.startswith(tj["kernel_tag"]):
-                    traffic, traffic_src = tj.get("bytes_per_launch"), os.path.relpath(tf, ROOT)
-            roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
-                        traffic_source=(f"{traffic_src}: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this command, "
-                                        "not measured in this run") if traffic_src else None,
-                        kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
-            import re
-            m_issued = re.search(r"MFMA work issued = ([0-9.]+) of the counted FLOPs", kname)
-            if m_issued:                                    # the kernel skips exact-zero work: say how much of the counted FLOPs the matrix cores execute
-                roof["mfma_work_issued_share"] = float(m_issued.group(1))
-                roof["frac_of_peak_issued"] = roof["frac"] * float(m_issued.group(1))
-                roof["issued_note"] = ("achieved / frac price the ALGORITHMIC FLOPs of the dense 3x3 convolutions (SURVEY 8d); the kernel leaves out the MFMA tiles whose "
-                                       "16 cells all read zero padding on a tap (exact zeros, results bit-identical), so the matrix cores execute "
-                                       "mfma_work_issued_share of them: frac_of_peak_issued is the hardware rate, frac the useful rate")
-            if tm_fused is not None and tm_fused["n_dominant"] > 0:
-                f_ms = tm_fused["ms_dominant"] / tm_fused["n_dominant"]
-                roof["measured_in"] = (f"a second timed segment of this run ({args.waves_per_step} waves, HIP events on every 8th) with the tree step and the "
-                                       "trunk launched as separate kernels; the headline segment runs them as ONE launch, see fused_launch")
-                roof["fused_launch"] = dict(kernel=kname_fused, avg_launch_us=f_ms * 1e3, launches=int(tm_fused["n_dominant"]),
-                                            frac_if_priced_as_mfma_only=kflops / (f_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                                            note="duration of tree step + trunk in one launch during the headline segment: the tree step's "
-                                                 "slowest games (a latency-bound pointer chase) are partly hidden behind the trunk's first workgroups")
-        label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[args.config]
-        out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
-                   value=positions / dt, unit="positions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="bf16", data="synthetic" if not emu else "synthetic — EMULATION BUILD ON CPU (launcher test), NOT A MEASUREMENT",
-                   config=dict(workload=f"{label}, {G} concurrent games/GPU, {args.sims} sims/move (MCTS.run iteration_limit), "
-                                        f"{args.blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
-                               games_per_gpu=G, sims_per_move=args.sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
-                               parallelism=f"games sharded x{world} (rank r owns global slots [r G, (r + 1) G)), counters all-reduced"),
-                   detail=dict(positions=positions, positions_per_rank=[int(x) for x in per_rank], games_finished=games,
-                               evaluator_calls=evals, simulations=sims,
-                               evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=sims / dt,
-                               eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
-                               eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
-                               fused_tree_and_trunk_launch=fused,
-                               ms_tree_kernel_per_wave=tm["ms_tree"] / max(tm["n_waves"], 1),
-                               ms_evaluator_per_wave=tm["ms_eval"] / max(tm["n_waves"], 1),
-                               per_wave_note=("tree / evaluator ms per wave come from the unfused timing segment" if tm_fused is not None else None)),
-                   roofline=roof)
+        out = None
+        if rank == 0:
+            HWc = net.H * net.W if net is not None else 0
+            fl = (flops_per_position(blocks, H=net.H, W=net.W) if game == "Connect4" else dict(total=2.0 * HWc * 9 * 128 * 128 * 2 * blocks)) if net is not None else dict(total=0.0)
+            roof = None
+            if use_net and tm["n_dominant"] > 0 and kflops > 0:
+                avg_ms = tm["ms_dominant"] / tm["n_dominant"]
+                ach = kflops / (avg_ms * 1e-3) / 1e12
+                traffic, traffic_src = None, None
+                # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this very command
+                # (tools/profile_round.sh -> tools/pmc_traffic.py); a PMC pass cannot run inside the timed process, so the figure is
+                # profile-derived and labelled as such.  Only quoted for the workload it was collected on.
+                import glob
+                for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_trunk_traffic.json"))):
+                    tj = json.load(open(tf))
+                    if config == "connect4" and G == 4096 and tj.get("kernel_tag") and kname.startswith(tj["kernel_tag"]):
+                        traffic, traffic_src = tj.get("bytes_per_launch"), os.path.relpath(tf, ROOT)
+                roof = dict(bound="mfma", achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS, traffic=traffic,
+                            traffic_source=(f"{traffic_src}: FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes of this command, "
+                                            "not measured in this run") if traffic_src else None,
+                            kernel=kname, flops_per_launch=kflops, avg_launch_us=avg_ms * 1e3, launches=int(tm["n_dominant"]))
+                import re
+                m_issued = re.search(r"MFMA work issued = ([0-9.]+) of the counted FLOPs", kname)
+                if m_issued:                                    # the kernel skips exact-zero work: say how much of the counted FLOPs the matrix cores execute
+                    roof["mfma_work_issued_share"] = float(m_issued.group(1))
+                    roof["frac_of_peak_issued"] = roof["frac"] * float(m_issued.group(1))
+                    roof["issued_note"] = ("achieved / frac price the ALGORITHMIC FLOPs of the dense 3x3 convolutions (SURVEY 8d); the kernel leaves out the MFMA tiles whose "
+                                           "16 cells all read zero padding on a tap (exact zeros, results bit-identical), so the matrix cores execute "
+                                           "mfma_work_issued_share of them: frac_of_peak_issued is the hardware rate, frac the useful rate")
+                if tm_fused is not None and tm_fused["n_dominant"] > 0:
+                    f_ms = tm_fused["ms_dominant"] / tm_fused["n_dominant"]
+                    roof["measured_in"] = (f"a second timed segment of this run ({args.waves_per_step} waves, HIP events on every 8th) with the tree step and the "
+                                           "trunk launched as separate kernels; the headline segment runs them as ONE launch, see fused_launch")
+                    roof["fused_launch"] = dict(kernel=kname_fused, avg_launch_us=f_ms * 1e3, launches=int(tm_fused["n_dominant"]),
+                                                frac_if_priced_as_mfma_only=kflops / (f_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                                note="duration of tree step + trunk in one launch during the headline segment: the tree step's "
+                                                     "slowest games (a latency-bound pointer chase) are partly hidden behind the trunk's first workgroups")
+            # the tree kernel against ITS roofline (north_star: "rocprof HBM GB/s on tree kernels"): algorithmic bytes per launch = SURVEY 8d's bytes per
+            # simulation x the simulations one launch runs (measured), over the launch duration of the separately-launched tree step (HIP events);
+            # counter bytes from the committed --pmc passes.  It is a chain of dependent round trips, not a stream: the fraction says so.
+            roof_tree = None
+            tw = max(tm["n_waves"], 1)
+            if tm["ms_tree"] > 0 and game in TREE_BYTES_PER_SIM:
+                sims_per_launch = n_sims / world / max(steps * args.waves_per_step, 1)        # per rank = per launch
+                t_us = tm["ms_tree"] / tw * 1e3
+                alg = TREE_BYTES_PER_SIM[game] * sims_per_launch
+                ctr, ctr_src = None, None
+                import glob
+                for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tree_traffic.json"))):
+                    tj = json.load(open(tf))
+                    if config == "connect4" and G == 4096 and not gumbel and tj.get("bytes_per_launch"):
+                        ctr, ctr_src = tj["bytes_per_launch"], os.path.relpath(tf, ROOT)
+                exposed = None
+                if tm_fused is not None and tm_fused["n_dominant"] > 0 and roof:
+                    exposed = tm_fused["ms_dominant"] / tm_fused["n_dominant"] * 1e3 - roof["avg_launch_us"]
+                roof_tree = dict(bound="hbm", kernel="k_wave_gumbel" if gumbel else ("k_wave_teams (four games per wavefront)" if game != "Gomoku" else "k_wave"),
+                                 achieved=alg / (t_us * 1e-6) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=alg / (t_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                 algorithmic_bytes_per_launch=alg, bytes_per_simulation=TREE_BYTES_PER_SIM[game], simulations_per_launch=sims_per_launch,
+                                 avg_launch_us=t_us, traffic=ctr, traffic_source=ctr_src,
+                                 exposed_us_in_fused_launch=exposed,
+                                 note="latency-bound pointer chase (one dependent L2 / HBM round trip per tree level): the launch lasts as long as its slowest game, "
+                                      "so the HBM fraction is tiny by construction; what counts is how much of it the fused launch hides (exposed_us_in_fused_launch = "
+                                      "fused launch - trunk kernel alone)")
+            label = {"connect4": "Connect4 6x7", "gomoku": "Gomoku 15x15", "gumbel": "Connect4 6x7 Gumbel (m=7)"}[config]
+            out = dict(metric="self-play positions/sec (whole node), Connect4 200 sims/move, 1/2/4/8 GPU",
+                       value=positions / dt, unit="positions/s", n_gpus=world, steps=steps, warmup=warmup,
+                       ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                       dtype="bf16", data="synthetic" if not emu else "synthetic — EMULATION BUILD ON CPU (launcher test), NOT A MEASUREMENT",
+                       config=dict(workload=f"{label}, {G} concurrent games/GPU, {sims} sims/move (MCTS.run iteration_limit), "
+                                            f"{blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
+                                   games_per_gpu=G, sims_per_move=sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
+                                   start=("every slot's first game starts at a random ply of a seeded random playout (games out of step from the first timed wave: "
+                                          "steady state); later games start at ply 0 as they restart on device") if args.stagger else "all games at ply 0",
+                                   parallelism=f"games sharded x{world} (rank r owns global slots [r G, (r + 1) G)), counters all-reduced"),
+                       detail=dict(positions=positions, positions_per_rank=[int(x) for x in per_rank],
+                                   positions_per_rank_min=int(per_rank.min()), positions_per_rank_max=int(per_rank.max()),
+                                   counters_allreduce_ms=t_red * 1e3, games_finished=games,
+                                   evaluator_calls=evals, simulations=n_sims,
+                                   evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=n_sims / dt,
+                                   eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
+                                   eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
+                                   fused_tree_and_trunk_launch=fused, fused_launch_faults=faults,
+                                   ms_tree_kernel_per_wave=tm["ms_tree"] / tw,
+                                   ms_evaluator_per_wave=tm["ms_eval"] / tw,
+                                   per_wave_note=("tree / evaluator ms per wave come from the unfused timing segment" if tm_fused is not None else None)),
+                       roofline=roof, roofline_tree=roof_tree)
 
-    # ---- extra legs (never the headline value) -------------------------------------------------------------------------
-    # (1) the same workload with the on-device evaluation cache (SURVEY 8f rank 3; the reference's Connect4 config runs its
-    #     Session_Cache too).  Search results are bit-identical; repeated states are answered from HBM inside the tree kernel.
-    if args.cache_leg and args.eval_cache == 0 and use_net:
-        e2 = make_engine(args.sims, args.cache_leg)
-        dt2, d2 = timed_run(e2, False)
-        t2 = reduce_stats(d2, world)
-        e2.close()
-        if rank == 0:
-            out["with_eval_cache"] = dict(value=int(t2[0]) / dt2, unit="positions/s", entries_log2=args.cache_leg,
-                                          hit_fraction=int(t2[4]) / max(int(t2[2]), 1), ms_per_step=dt2 / args.steps * 1e3,
-                                          note="same search results bit for bit; NOT the headline value")
-    # (2) the reference's own convention: Self_Play passes int(1.5 * MCTS_iteration_limit) to MCTS.run (Self_Play.py:99), so a
-    #     config that says "200" runs 300 simulations per move there (SURVEY 8d second line).
-    ref_leg = args.ref_convention_leg if args.ref_convention_leg >= 0 else int(args.config == "connect4" and world == 1 and not gumbel)
-    if ref_leg and not gumbel:
-        sims3 = int(args.sims * 1.5)
-        e3 = make_engine(sims3, args.eval_cache)
-        dt3, d3 = timed_run(e3, False)
-        t3 = reduce_stats(d3, world)
-        e3.close()
-        if rank == 0:
-            out["reference_convention"] = dict(value=int(t3[0]) / dt3, unit="positions/s", sims_per_move=sims3,
-                                               evals_per_position=int(t3[2]) / max(int(t3[0]), 1), ms_per_step=dt3 / args.steps * 1e3,
-                                               note=f"MCTS_iteration_limit = {args.sims} as Self_Play runs it: int(1.5 * limit) = {sims3} simulations per "
-                                                    "move (Self_Play.py:99); NOT the headline value")
+        # ---- extra legs (never the headline value) -------------------------------------------------------------------------
+        # (1) the same workload with the on-device evaluation cache (SURVEY 8f rank 3; the reference's Connect4 config runs its
+        #     Session_Cache too).  Search results are bit-identical; repeated states are answered from HBM inside the tree kernel.
+        if legs and cache_leg and args.eval_cache == 0 and use_net:
+            e2 = make_engine(sims, cache_leg)
+            dt2, d2 = timed_run(e2, False)
+            t2 = reduce_stats(d2[:5], world)
+            e2.close()
+            if rank == 0:
+                out["with_eval_cache"] = dict(value=int(t2[0]) / dt2, unit="positions/s", entries_log2=cache_leg,
+                                              hit_fraction=int(t2[4]) / max(int(t2[2]), 1), ms_per_step=dt2 / steps * 1e3,
+                                              note="same search results bit for bit; NOT the headline value")
+        # (2) the reference's own convention: Self_Play passes int(1.5 * MCTS_iteration_limit) to MCTS.run (Self_Play.py:99), so a
+        #     config that says "200" runs 300 simulations per move there (SURVEY 8d second line).
+        ref_leg = args.ref_convention_leg if args.ref_convention_leg >= 0 else int(config == "connect4" and world == 1 and not gumbel)
+        if legs and ref_leg and not gumbel:
+            sims3 = int(sims * 1.5)
+            e3 = make_engine(sims3, args.eval_cache)
+            dt3, d3 = timed_run(e3, False)
+            t3 = reduce_stats(d3[:5], world)
+            e3.close()
+            if rank == 0:
+                out["reference_convention"] = dict(value=int(t3[0]) / dt3, unit="positions/s", sims_per_move=sims3,
+                                                   evals_per_position=int(t3[2]) / max(int(t3[0]), 1), ms_per_step=dt3 / steps * 1e3,
+                                                   note=f"MCTS_iteration_limit = {sims} as Self_Play runs it: int(1.5 * limit) = {sims3} simulations per "
+                                                        "move (Self_Play.py:99); NOT the headline value")
+        return out, net
+
+    out, net = measure(args.config, args.games, args.sims, args.blocks, args.steps, args.warmup, legs=True)
+    # ---- BASELINE configs[3] and configs[4] in the same command (VERDICT r2 item 3): their own workloads, their own rooflines (priced per launch)
+    # and evaluations per position; shorter timed regions (a Gomoku wave is six times a Connect4 wave).  Never the headline value.
+    other = args.other_configs if args.other_configs >= 0 else int(args.config == "connect4" and world == 1 and not emu and args.games == 0 and args.sims == 0 and args.blocks == 0)
+    if other:
+        for name, steps, warm in (("gumbel", max(2, args.steps // 2), max(1, args.warmup // 2)), ("gomoku", max(2, args.steps // 4), 1)):
+            o2, _ = measure(name, 0, 0, 0, steps, warm, legs=False)
+            if rank == 0:
+                keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_tree")
+                out[name] = {k: o2[k] for k in keep}
+                out[name]["evals_per_position"] = o2["detail"]["evals_per_position"]
+                out[name]["evals_per_s"] = o2["detail"]["evals_per_s"]
+                out[name]["ms_tree_kernel_per_wave"] = o2["detail"]["ms_tree_kernel_per_wave"]
+                out[name]["ms_evaluator_per_wave"] = o2["detail"]["ms_evaluator_per_wave"]
+                out[name]["note"] = f"BASELINE.json configs[{4 if name == 'gumbel' else 3}] measured by the same command; NOT the headline value"
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.config == "connect4" and not emu:
+        args.sims = args.sims or CONFIGS["connect4"][2]
         out["cpu_baseline"] = cpu_baseline(args, net)
     if rank == 0:
         print(json.dumps(out), flush=True)

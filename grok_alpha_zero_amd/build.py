@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "gaz_engine.h")
 UNITS = {
     "engine.hip": ["rt.hpp", "wave.hpp", "det.hpp", "games.hpp", "tree.hpp", "puct_core.hpp", "gumbel_core.hpp", "evaluator.hpp"],
     "resnet.hip": ["rt.hpp", "wave.hpp", "evaluator.hpp", "netops.hpp", "conv3x3.hpp", "resblock.hpp", "trunk.hpp", "tile_perm.hpp",
-                   "det.hpp", "games.hpp", "tree.hpp", "puct_core.hpp"],          # the fused tree + trunk launch lives in resnet.hip
+                   "det.hpp", "games.hpp", "tree.hpp", "puct_core.hpp", "gumbel_core.hpp"],          # the fused tree + trunk launch lives in resnet.hip
 }
 # -ffp-contract=off: the injected-noise samplers and PUCT scores must not be FMA-contracted (bit parity)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value",

@@ -181,9 +181,22 @@ template <class G> GAZ_KERNEL_WIDE k_move_slots(DevParams<G> E, const int32_t* m
     copy1(E.nn_in + (size_t)dst * (G::HW * G::C), E.nn_in + (size_t)src * (G::HW * G::C), G::HW * G::C);
     copy1(E.nn_policy + (size_t)dst * G::A, E.nn_policy + (size_t)src * G::A, 4 * G::A);
     copy1(E.nn_value + dst, E.nn_value + src, 4);
+    if (E.eval_skipped) copy1(E.eval_skipped + dst, E.eval_skipped + src, 4);
     // swap the two GameStates word by word (each thread its own words: no staging needed)
     uint32_t* ga = reinterpret_cast<uint32_t*>(&E.games[src]); uint32_t* gb = reinterpret_cast<uint32_t*>(&E.games[dst]);
     for (size_t i = t; i < sizeof(GameState<G>) / 4; i += T) { const uint32_t x = ga[i]; ga[i] = gb[i]; gb[i] = x; }
+}
+
+// gaz_engine_debug_fused_fault on a path without the fused launch (other games / searches / the CPU emulation build): what a trunk workgroup
+// that gave up leaves behind — its boards marked with the wave's epoch, their outputs NOT those of this wave's requests (poisoned here, so that
+// a tree step that consumed them could not go unnoticed), the fault counter raised.
+template <class G> GAZ_KERNEL k_debug_skip(DevParams<G> E, int n, unsigned mod, int32_t* fault) {
+    const int g = block_id();
+    if (g >= n || lane_id() != 0 || !E.eval_skipped || (unsigned)(g / 3) % mod != 1u) return;
+    E.eval_skipped[g] = E.wave_epoch;
+    for (int a = 0; a < G::A; ++a) E.nn_policy[(size_t)g * G::A + a] = __builtin_nanf("");
+    E.nn_value[g] = __builtin_nanf("");
+    if (g % 3 == 0 || g == 0) atomic_add(fault, (int32_t)1);
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
@@ -260,6 +273,7 @@ struct gaz_engine {
     virtual int set_hyperparams(const gaz_search_hyperparams*) = 0;
     virtual int read_head_features(int, float*, float*, int32_t*, int32_t*) = 0;
     virtual int set_fused_wave(int) = 0;
+    virtual int debug_fused_fault(int) = 0;
     virtual int repack(int32_t*, int32_t*) = 0;
     virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
@@ -425,6 +439,8 @@ template <class G> struct EngineT : gaz_engine {
     }
 
     int reset_games(const int32_t* slots, int n) override {
+        if (slots && n_eff != E.n_games) return fail("reset_games(slots): not after gaz_engine_repack (a physical slot no longer identifies a game; reset all games instead)");
+        if (!slots) n_eff = E.n_games;               // every slot restarts: the launches cover all of them again
         if (slots) {
             if (n > E.n_games) return fail("reset_games: too many slots");
             HIP_OK(hipMemcpyAsync(dSlots, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
@@ -439,7 +455,10 @@ template <class G> struct EngineT : gaz_engine {
     hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
     static constexpr size_t MAX_TIMING_EVENTS = 1 << 16;            // a timed run of any length holds at most this many events
 
-    void launch_wave(hipStream_t st, int g0, int g1) {
+    // every tree launch carries the wave's epoch once a fused launch may have left rows out (DevParams::eval_skipped)
+    DevParams<G> wave_params() { DevParams<G> P = E; if (E.eval_skipped) P.wave_epoch = ++fuse_epoch; return P; }
+    void launch_wave(hipStream_t st, int g0, int g1) { launch_wave(st, g0, g1, wave_params()); }
+    void launch_wave(hipStream_t st, int g0, int g1, const DevParams<G>& E) {
         // the small boards run four games per wavefront (PuctVariant: same records, 16-lane teams); GAZ_TREE_TEAMS=0 -> one per wave
         typedef typename PuctVariant<G>::type GP;
         if (cfg.search == GAZ_SEARCH_GUMBEL) {
@@ -463,7 +482,27 @@ template <class G> struct EngineT : gaz_engine {
 
     // ---- fused tree + trunk launch (resnet.hip k_wave_trunk): Connect4 PUCT with the whole-trunk ResNet evaluator, no evaluation
     // cache (its probe reads rows other teams are writing).  GAZ_FUSE_WAVE=0 -> separate launches.
-    uint32_t* d_done = nullptr; uint32_t fuse_epoch = 0; int fuse_state = -1;     // -1 not decided, 0 off, 1 on
+    // The hand-over inside the launch is BOUNDED (trunk.hpp TrunkArgs::spin_ticks): HIP promises no dispatch order, so a trunk workgroup whose
+    // games' tree block is not resident may not wait forever.  A workgroup that gives up marks its boards in d_skipped and counts itself in
+    // d_fault; the games keep their requests pending (no result changes), and poll_fuse_fault() — at every host synchronisation point —
+    // switches this engine to separate launches for good.
+    uint32_t* d_done = nullptr; uint32_t* d_skipped = nullptr; int32_t* d_fault = nullptr;
+    uint32_t fuse_epoch = 0; int fuse_state = -1;     // -1 not decided, 0 off, 1 on
+    uint64_t fuse_faults = 0;                        // trunk workgroups that gave up waiting, over the engine's life (get_stats [13])
+    unsigned debug_fault_mod = 0;                    // test hook: gaz_engine_debug_fused_fault
+    static constexpr unsigned SPIN_TICKS = 2000000;  // 20 ms of the 100-MHz wall clock; a tree step takes ~0.1 ms
+    int poll_fuse_fault() {                          // stream must be idle
+        if (!d_fault) return 0;
+        int32_t n = 0;
+        HIP_OK(hipMemcpy(&n, d_fault, sizeof(n), hipMemcpyDeviceToHost));
+        if (n) {
+            fuse_faults += (uint64_t)n; n = 0; fuse_state = 0; debug_fault_mod = 0;      // (the test hook injects until the fault has been seen)
+            HIP_OK(hipMemcpy(d_fault, &n, sizeof(n), hipMemcpyHostToDevice));
+            fprintf(stderr, "[gaz_engine] fused tree + trunk launch: %llu trunk workgroup(s) gave up waiting for their games (dispatch order not as assumed); "
+                            "falling back to separate launches\n", (unsigned long long)fuse_faults);
+        }
+        return 0;
+    }
     bool can_fuse() {
         if (fuse_state >= 0) return fuse_state == 1;
         fuse_state = 0;
@@ -474,13 +513,24 @@ template <class G> struct EngineT : gaz_engine {
         static const bool with_cache = !(getenv("GAZ_FUSE_CACHE") && atoi(getenv("GAZ_FUSE_CACHE")) == 0);
         if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || cfg.search != GAZ_SEARCH_PUCT || (E.cache && !with_cache) || E.compact || !eval || !eval->supports_split()) return false;
         if (getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
-        if (dalloc(&d_done, (size_t)E.n_games)) return false;
+        if (dalloc(&d_done, (size_t)E.n_games) || !ensure_skip_buffers()) return false;
         fuse_state = 1;
         return true;
     }
 
     bool fuse_enabled = true;
     int set_fused_wave(int on) override { fuse_enabled = on != 0; return 0; }
+    bool ensure_skip_buffers() {
+        if (d_skipped) return true;
+        if (dalloc(&d_skipped, (size_t)E.n_games) || dalloc(&d_fault, 4)) return false;
+        E.eval_skipped = d_skipped;
+        return true;
+    }
+    int debug_fused_fault(int mod) override {
+        if (mod > 0 && !ensure_skip_buffers()) return 1;
+        debug_fault_mod = mod > 0 ? (unsigned)mod : 0u;
+        return 0;
+    }
 
     // ---- repack (continuous self-play with a games_budget): towards the end of a generation more and more slots have played their
     // last game and halted, but every wave still steps and EVALUATES all n_games rows.  repack() moves the games that still run into
@@ -530,7 +580,8 @@ template <class G> struct EngineT : gaz_engine {
     int one_wave(bool with_eval) {
         if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
-            const void* plan = eval->trunk_plan(E.nn_in, n_eff, 0, d_done, fuse_epoch + 1);
+            const FuseHandoff ho{d_done, fuse_epoch + 1, d_skipped, d_fault, SPIN_TICKS, debug_fault_mod};
+            const void* plan = eval->trunk_plan(E.nn_in, n_eff, 0, ho);
             if (plan) {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
                 if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
@@ -538,7 +589,7 @@ template <class G> struct EngineT : gaz_engine {
                 launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
                 if (timing) hipEventRecord(e1, stream);
                 eval->forward_heads(stream, E.nn_policy, E.nn_value, n_eff, 0);
-                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, E, 0, n_eff); E.cache_epoch++; }
+                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, Ef, 0, n_eff); E.cache_epoch++; }
                 if (timing) {       // the fused kernel is booked as evaluator time; tree time is what it hides
                     hipEventRecord(e2, stream); ev_eval.push_back({e0, e2}); n_waves_timed++;
                     ev_fused.push_back({e0, e1});
@@ -552,11 +603,13 @@ template <class G> struct EngineT : gaz_engine {
         const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
-        launch_wave();
+        const DevParams<G> P = wave_params();
+        launch_wave(stream, 0, n_eff, P);
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, n_eff, timing);
         if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); n_waves_timed++; }
-        if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, E, 0, n_eff); E.cache_epoch++; }
+        if (with_eval && eval && debug_fault_mod && E.eval_skipped) GAZ_LAUNCH(k_debug_skip<G>, n_eff, WAVE, stream, P, n_eff, debug_fault_mod, d_fault);
+        if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, P, 0, n_eff); E.cache_epoch++; }
         n_waves_total++;
         return 0;
     }
@@ -606,13 +659,14 @@ template <class G> struct EngineT : gaz_engine {
         hipStreamWaitEvent(tstream, ev_join, 0); hipStreamWaitEvent(hstream, ev_join, 0);
         for (int k = 0; k < n; ++k) {
             const int cur = k & 1, prev = cur ^ 1;
-            const bool timed = timing && n_waves_total % TIMING_STRIDE == 0;
+            const bool timed = timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 2 * (size_t)n_grp <= MAX_TIMING_EVENTS;
+            const DevParams<G> P = wave_params();                         // one epoch per wave, whatever the number of groups
             for (int g = 0; g < n_grp; ++g) {
                 const int g0 = grp0[g], g1 = grp0[g + 1];
                 if (k > 0) hipStreamWaitEvent(tstream, ev_heads_done[prev][g], 0);      // this group's previous evaluation
                 hipEvent_t t0 = 0, t1 = 0;
                 if (timed) { t0 = new_event(); t1 = new_event(); hipEventRecord(t0, tstream); }
-                launch_wave(tstream, g0, g1);
+                launch_wave(tstream, g0, g1, P);
                 if (timed) { hipEventRecord(t1, tstream); ev_tree.push_back({t0, t1}); }
                 hipEventRecord(ev_tree_done[cur][g], tstream);
                 hipStreamWaitEvent(stream, ev_tree_done[cur][g], 0);
@@ -786,11 +840,13 @@ template <class G> struct EngineT : gaz_engine {
         memcpy(&out[6], c + 2, 8); memcpy(&out[7], c + 4, 8); memcpy(&out[8], c + 6, 8);
         out[9] = (uint64_t)n_waves_total; memcpy(&out[10], c + 8, 8);
         out[11] = pipeline_ready ? (uint64_t)n_grp : 0;
+        if (poll_fuse_fault()) return 1;             // counts() synchronised the stream
         out[12] = (fuse_state == 1 && fuse_enabled) ? 1 : 0;
+        out[13] = fuse_faults;
         return check_device_error();
     }
 
-    int synchronize() override { HIP_OK(hipStreamSynchronize(stream)); return check_device_error(); }
+    int synchronize() override { HIP_OK(hipStreamSynchronize(stream)); if (poll_fuse_fault()) return 1; return check_device_error(); }
 
     int timing_reset(int enable) override {
         HIP_OK(hipStreamSynchronize(stream));
@@ -800,6 +856,7 @@ template <class G> struct EngineT : gaz_engine {
         return 0;
     }
     int set_position(int slot, const int32_t* actions, int n) override {
+        if (n_eff != E.n_games) return fail("set_position: not after gaz_engine_repack (a physical slot no longer identifies a game)");
         if (slot < 0 || slot >= E.n_games || n < 0 || n > G::MAXT) return fail("set_position: bad slot / history length");
         if (n > 0) HIP_OK(hipMemcpyAsync(dMoves, actions, sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));   // dMoves holds >= MAXT? n_games ints
         GAZ_LAUNCH(k_set_position<G>, 1, WAVE, stream, E, slot, (const int32_t*)dMoves, n);
@@ -835,6 +892,18 @@ template <class G> struct EngineT : gaz_engine {
         if (given(hp->dirichlet_alpha) && hp->dirichlet_alpha <= 0.0) return fail("dirichlet_alpha must be positive");
         if (given(hp->dirichlet_epsilon) && (hp->dirichlet_epsilon < 0.0 || hp->dirichlet_epsilon >= 1.0)) return fail("dirichlet_epsilon must be in [0, 1)");
         if (hp->gumbel_m >= 0 && cfg.search == GAZ_SEARCH_GUMBEL && hp->gumbel_m < 2) return fail("Gumbel search needs m >= 2");
+        // the node arena was sized at create time from run_iterations (and gumbel_m): a larger value now could only end in ERR_ARENA_FULL in
+        // the middle of a search, so it is refused here with the remedy
+        if (cfg.nodes_per_tree <= 0) {
+            const int it = hp->run_iterations > 0 ? hp->run_iterations : E.run_iterations, m = hp->gumbel_m >= 0 ? hp->gumbel_m : E.gumbel_m;
+            long long need = 0;
+            if (cfg.search == GAZ_SEARCH_GUMBEL) need = 2LL * (it + m) + 3 * G::A + 64;
+            else if (E.compact) need = 4LL * (it < 3 * G::A ? 3 * G::A : it) + 3 * G::A + 64;
+            else need = (long long)((cfg.max_actions + 1) / 2 + 1) * ((it < 3 * G::A ? 3 * G::A : it) + 2) + 64;
+            if (need > E.nodes_per_tree)
+                return fail("set_hyperparams: run_iterations / gumbel_m beyond what the tree arena was sized for at create time (" + std::to_string(E.nodes_per_tree) +
+                            " nodes per tree, " + std::to_string(need) + " needed): create the engine with the largest values, or give nodes_per_tree");
+        }
         bool table = false;
         if (given(hp->c_puct_init)) { E.c_init = hp->c_puct_init; table = true; }
         if (given(hp->c_puct_base)) { E.c_base = hp->c_puct_base; table = true; }
@@ -961,6 +1030,7 @@ int gaz_engine_stop_search(gaz_engine* h, int32_t stop) { return h->stop_search(
 int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
 int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on) { return h->set_fused_wave(on); }
+int gaz_engine_debug_fused_fault(gaz_engine* h, int32_t mod) { return h->debug_fused_fault(mod); }
 int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch) { return h->repack(n_active, n_launch); }
 int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p, float* v, int32_t* p_row, int32_t* v_row) { return h->read_head_features(n, p, v, p_row, v_row); }
 int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,

@@ -12,6 +12,9 @@
 
 namespace gaz {
 
+// what a fused tree + trunk launch hands from the tree teams to the trunk workgroups (trunk.hpp TrunkArgs::ready ... test_fault_mod)
+struct FuseHandoff { const unsigned* ready; unsigned epoch; unsigned* skipped; int* fuse_fault; unsigned spin_ticks; unsigned test_fault_mod; };
+
 struct Evaluator {
     virtual ~Evaluator() {}
     virtual int load(const gaz_tensor* t, int n, hipStream_t s, std::string* err) { (void)t; (void)n; (void)s; (void)err; return 0; }
@@ -26,8 +29,8 @@ struct Evaluator {
     virtual void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int p0) { (void)s; (void)in; (void)n; (void)timing; (void)p0; }
     virtual void forward_heads(hipStream_t s, float* policy, float* value, int n, int p0) { (void)s; (void)policy; (void)value; (void)n; (void)p0; }
     // fused tree + trunk launch (resnet.hip k_wave_trunk): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
-    // planes of board b are valid once ready[b] == epoch.  Null = this evaluator / configuration cannot be fused.
-    virtual const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) { (void)in; (void)n; (void)p0; (void)ready; (void)epoch; return nullptr; }
+    // planes of board b are valid once ready[b] == epoch (FuseHandoff, below).  Null = this evaluator / configuration cannot be fused.
+    virtual const void* trunk_plan(const int8_t* in, int n, int p0, const struct FuseHandoff& h) { (void)in; (void)n; (void)p0; (void)h; return nullptr; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }
@@ -82,6 +85,8 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
 // resnet.hip k_wave_trunk: ONE launch = the PUCT tree step of Connect4 games [g0, g1) (16-lane teams) + the trunk kernel of their leaf rows.
 // dev_params: DevParams<TeamGame<GAME_C4>> by value; plan: what Evaluator::trunk_plan returned.  false = not launched.
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
+// the same for the Gumbel search (MCTS_Gumbel.py:562-679) of Connect4: one wavefront per game, four games per tree block.  dev_params: DevParams<Game<GAME_C4>>
+bool launch_wave_trunk_c4_gumbel(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
 
 inline Evaluator* make_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err) {
     if (cfg.evaluator == GAZ_EVAL_HASH) return new HashEvaluator(H * W * C, A, cfg.hash_salt);

@@ -672,6 +672,7 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
     GameState<G>* gsG = &E.games[g];
     GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
     TreeState* tsG = &E.trees[(size_t)g * 2];
+    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g); return; }      // see puct_core.hpp game_step
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.gu, guG); copy_state_words<G>(&L.ts, tsG);
     wave_sync();

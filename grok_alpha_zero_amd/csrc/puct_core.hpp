@@ -75,6 +75,10 @@ template <class G> struct DevParams {
     // workgroups of the SAME launch can start on their boards while slower games are still searching.  Null = plain launches.
     uint32_t* done_flag;       // [n_games] epoch of the last launch that finished the game's tree step
     uint32_t wave_epoch;
+    // bounded hand-over (trunk.hpp TrunkArgs::skipped): a trunk workgroup whose wait for done_flag ran out of time leaves its boards unevaluated and
+    // writes the launch's epoch here; the game's next tree step then keeps its request pending (the leaf row is still in nn_in) instead of
+    // consuming outputs that were never computed.  A game only loses a wave: its results cannot change.  Null = never fused.
+    uint32_t* eval_skipped;    // [n_games]
 };
 
 // stores / loads that meet at the device's point of coherence (no L1 / per-XCD L2 copy): used for the leaf rows and the done flags
@@ -555,6 +559,7 @@ template <class G> GAZ_DEV const uint8_t* cache_probe(const DevParams<G>& E, int
 template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
     using CL = CacheLayout<G>;
     if (tuni<G>(E.games[g].pend_kind) == PEND_NONE) return;
+    if (E.eval_skipped && tuni<G>(E.eval_skipped[g]) == E.wave_epoch && E.wave_epoch) return;     // this wave's evaluator left the row out: nothing to store
     const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
     const uint64_t h = mix64(row_hash<G>(row));
     const uint32_t slot = (uint32_t)h & E.cache_mask;
@@ -1060,14 +1065,24 @@ template <class G, class T> GAZ_DEV void copy_state_words(T* dst, const T* src) 
 template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g) {
 #ifndef GAZ_HOST_EMU
     if (!E.done_flag) return;
-    __builtin_amdgcn_s_waitcnt(0);                  // vmcnt(0): every store of this wave — the leaf row included — has been acknowledged
+    // every store of this wave — the leaf row included — has been acknowledged before the flag is written.  Inline asm with a memory clobber: the
+    // compiler may neither sink a row store below it nor hoist the flag store above it (MI355X_MICROARCH.md, Valid forms: write-through payload ->
+    // asm vmcnt(0) -> flag), which a relaxed atomic + the waitcnt builtin alone would not forbid.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tlane<G>() == 0) store_coherent(reinterpret_cast<int*>(E.done_flag + g), (int)E.wave_epoch);
 #endif
+}
+
+// did the evaluator leave game g's row out in the previous wave (see DevParams::eval_skipped)?  Team-uniform.
+template <class G> GAZ_DEV bool eval_was_skipped(const DevParams<G>& E, int g) {
+    if (!E.eval_skipped || E.wave_epoch < 2) return false;
+    return tuni<G>(E.eval_skipped[g]) == E.wave_epoch - 1;
 }
 
 template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {
     GameState<G>* gsG = &E.games[g];
     TreeState* tsG = E.trees + (size_t)g * 2;
+    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g); return; }      // the request stays pending: same leaf row, evaluated by this wave
     if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); publish_done<G>(E, g); return; }
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.ts[0], &tsG[0]); copy_state_words<G>(&L.ts[1], &tsG[1]);

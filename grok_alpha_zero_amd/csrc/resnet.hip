@@ -26,6 +26,7 @@
 #include "trunk.hpp"
 #include "tile_perm.hpp"
 #include "puct_core.hpp"      // the fused tree + trunk launch at the end of this file steps the games with the tree kernel's device code
+#include "gumbel_core.hpp"
 
 namespace gaz {
 
@@ -604,9 +605,10 @@ struct ResNetEvaluator : Evaluator {
         return true;
     }
     TrunkLaunchPlan fused_plan;
-    const void* trunk_plan(const int8_t* in, int n, int p0, const unsigned* ready, unsigned epoch) override {
+    const void* trunk_plan(const int8_t* in, int n, int p0, const FuseHandoff& h) override {
         if (!trunk_m16 || !make_trunk_plan(in, n, p0, fused_plan)) return nullptr;
-        fused_plan.args.ready = ready; fused_plan.args.epoch = epoch;
+        TrunkArgs& r = fused_plan.args;
+        r.ready = h.ready; r.epoch = h.epoch; r.skipped = h.skipped; r.fuse_fault = h.fuse_fault; r.spin_ticks = h.spin_ticks; r.test_fault_mod = h.test_fault_mod;
         return &fused_plan;
     }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
@@ -773,7 +775,7 @@ struct GenericEvaluator : Evaluator {
     std::vector<void*> allocs; bool loaded = false; std::string lerr;
     bf16_t *X0 = nullptr, *A0 = nullptr, *X = nullptr, *Aa = nullptr, *Hh = nullptr, *Va = nullptr, *PH = nullptr, *VH = nullptr;
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr, *pd2 = nullptr, *vd2 = nullptr, *plog = nullptr;
-    std::vector<hipEvent_t> tev; int trunk_convs = 0;
+    std::vector<hipEvent_t> tev; int trunk_convs = 0; bool one_launch = false;   // one_launch: the bracket holds ONE kernel (the whole trunk, block 0 included)
     bool fused = true, block0_fused = false, block0_inplace = false; int n_cus = 256, fused_blocks = 0;
     hipStream_t side_stream = 0; hipEvent_t ev_fork = 0, ev_join = 0;     // value head next to the policy head (Gomoku)   // Gomoku: k_block0 + k_resblock3 (one kernel per block)
     bool trunk = true, trunk_m16 = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
@@ -960,7 +962,7 @@ struct GenericEvaluator : Evaluator {
         }
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
-        trunk_convs = 0; fused_blocks = 0;
+        trunk_convs = 0; fused_blocks = 0; one_launch = false;
         const bool fuse = gomoku && fused && blocks > 1;
         bf16_t* cur = X;                            // raw trunk activation after the last block
         for (int i = 0; i < blocks; ++i) {
@@ -970,7 +972,7 @@ struct GenericEvaluator : Evaluator {
                 TrunkArgs t; memset(&t, 0, sizeof(t));
                 t.x0 = X0; t.prm0 = trunk_prm0; t.xout = Hh; t.w = trunk_w0; t.prm = trunk_prm; t.M = M; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
                 hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), dim3(n), dim3(512), trunk_lds_bytes(256), s, t);
-                cur = Hh; fused_blocks += blocks; block0_fused = true;
+                cur = Hh; fused_blocks += blocks; block0_fused = true; one_launch = true;
                 break;
             }
             if (fuse && first && b16.count(b + ".w29")) {          // the 256 -> 128 block with its projection, one kernel (k_block0)
@@ -1084,15 +1086,20 @@ struct GenericEvaluator : Evaluator {
         for (size_t i = 0; i + 1 < tev.size(); i += 2) { float a = 0; hipEventElapsedTime(&a, tev[i], tev[i + 1]); t += a; }
         // launches of the dominant kernel inside the bracket: fused blocks (k_resblock3) or 128 -> 128 convs; block 0 of the
         // Gomoku net (256 -> 128 + projection) rides in the same bracket and is counted as one more launch-equivalent
-        *ms = t; *launches = (int64_t)(tev.size() / 2) * (fused_blocks > 0 ? fused_blocks + (block0_fused ? 0 : 1) : (trunk_convs > 0 ? trunk_convs : 1));
+        *ms = t; *launches = (int64_t)(tev.size() / 2) * (one_launch ? 1 : (fused_blocks > 0 ? fused_blocks + (block0_fused ? 0 : 1) : (trunk_convs > 0 ? trunk_convs : 1)));
     }
     const char* dominant_kernel(int n, double* flops) override {
         const double conv = 2.0 * (double)n * HW * 128.0 * 1152.0;
         if (!gomoku) { *flops = 0; return ""; }
         const bool fz = fused && blocks > 1;
         *flops = fz ? 2 * conv : conv;
-        if (fz && trunk && trunk_w && trunk_m16 && block0_in_trunk && trunk_w0)
-            return "k_trunk<8 waves, B0> (the whole trunk in one launch, block 0 with its projection included; priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16)";
+        if (fz && trunk && trunk_w && trunk_m16 && block0_in_trunk && trunk_w0 && HW <= 256) {
+            // priced per LAUNCH: the one kernel runs block 0 (3x3 256->128 = two 128-channel convolutions, 3x3 128->128, the 1x1
+            // projection 256->128) and blocks - 1 regular blocks of two 3x3 convolutions each
+            *flops = (2.0 * (blocks - 1) + 3.0) * conv + 2.0 * (double)n * HW * 256.0 * 128.0;
+            return "k_trunk<8 waves, B0> (the whole Gomoku trunk in ONE launch per forward: block 0 with its 256-channel input and 1x1 projection + the other residual blocks, "
+                   "every 3x3 / 1x1 convolution of them counted; implicit GEMM on v_mfma_f32_16x16x32_bf16, activations resident in LDS)";
+        }
         if (fz && trunk && trunk_w) return trunk_m16 ? "k_trunk<RESG, 8 waves> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_16x16x32_bf16)"
                                                      : "k_trunk<4,2,RESG> (blocks 1.. in one launch, priced per residual block: two 3x3 convs 128->128, implicit GEMM on v_mfma_f32_32x32x16_bf16)";
         return fz ? "k_resblock3 (whole residual block: two 3x3 convs 128->128, implicit GEMM on MFMA 32x32x16 bf16)"
@@ -1189,23 +1196,39 @@ namespace gaz {
 
 typedef TeamGame<GAME_C4> GP4;
 
-template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+// The tree role is a FUNCTION CALL, not inlined code: inlined, its scalar-register pressure (337 spilled SGPRs, parked in lanes of 6 VGPRs that
+// are then reserved for the whole kernel) pushed the trunk role of the edge-tile variant from 252 to 256 VGPRs + 7 spilled ones (32 B of scratch
+// per lane, read and written inside its block loop).  One call per tree block; the callee allocates its own registers.
+template <class GP, class LOCAL, bool GUMBEL> __device__ __attribute__((noinline)) void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
+    constexpr int PER = WAVE / GP::TEAM, NT = (TR_THREADS / WAVE) * PER;
+    Scratch<GP>* S = reinterpret_cast<Scratch<GP>*>(lds);
+    LOCAL* L = reinterpret_cast<LOCAL*>(S + NT);
+    static_assert(NT * (sizeof(Scratch<GP>) + sizeof(LOCAL)) <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
+    const int w = threadIdx.x >> 6, t = team_in_wave<GP>(), i = w * PER + t;
+    const int g = g0 + ((int)blockIdx.x * (TR_THREADS / WAVE) + w) * PER + t;
+    if (g < g1) {
+        if constexpr (GUMBEL) g_game_step<GP>(E, g, S[i], L[i]);
+        else game_step<GP>(E, g, S[i], L[i]);
+    }
+}
+
+template <bool MIX, bool SKIP, class GP, class LOCAL, bool GUMBEL>
+__device__ __forceinline__ void wave_trunk_body(const DevParams<GP>& E, int g0, int g1, int n_tree_blocks, const TrunkArgs& a) {
     if ((int)blockIdx.x < n_tree_blocks) {
         // ---- tree role: wave w of the block steps games [(4 b + w) PER, +PER); its scratch lives in the launch's dynamic LDS
-        constexpr int PER = WAVE / GP4::TEAM, NT = (TR_THREADS / WAVE) * PER;
         extern __shared__ uint4 lds[];
-        Scratch<GP4>* S = reinterpret_cast<Scratch<GP4>*>(lds);
-        PuctLocal<GP4>* L = reinterpret_cast<PuctLocal<GP4>*>(S + NT);
-        static_assert(NT * (sizeof(Scratch<GP4>) + sizeof(PuctLocal<GP4>)) <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
-        const int w = threadIdx.x >> 6, t = team_in_wave<GP4>(), i = w * PER + t;
-        const int g = g0 + ((int)blockIdx.x * (TR_THREADS / WAVE) + w) * PER + t;
-        if (g < g1) game_step<GP4>(E, g, S[i], L[i]);
+        const DevParams<GP> El = E;                 // the callee takes an address: copy the kernel argument to the stack HERE, not at kernel entry for every workgroup
+        tree_role<GP, LOCAL, GUMBEL>(El, g0, g1, lds);
         return;
     }
     // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid
     const int bid = (int)blockIdx.x - n_tree_blocks;
     if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr);
     else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr);
+}
+
+template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+    wave_trunk_body<MIX, SKIP, GP4, PuctLocal<GP4>, false>(E, g0, g1, n_tree_blocks, a);
 }
 
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {

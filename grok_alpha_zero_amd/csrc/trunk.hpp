@@ -34,6 +34,12 @@ struct TrunkArgs {
     // fused tree + trunk launch (resnet.hip k_wave_trunk): board b's planes are valid once ready[b] has reached `epoch` (written by the tree team
     // of game b in this very launch); null = the planes were complete before the launch
     const unsigned* ready; unsigned epoch;
+    // ... and the wait is BOUNDED: HIP promises no dispatch order, so a tree block of this launch may not be resident yet (or ever, while every
+    // slot is held by a waiting trunk workgroup).  After spin_ticks of the 100-MHz wall clock — or at once when an earlier workgroup has already
+    // given up (*fuse_fault != 0) — the workgroup leaves its boards unevaluated, writes `epoch` to skipped[board] and counts itself in
+    // *fuse_fault; the games re-request (DevParams::eval_skipped) and the host falls back to separate launches (engine.hip poll_fuse_fault).
+    unsigned* skipped; int* fuse_fault; unsigned spin_ticks;
+    unsigned test_fault_mod;                        // test hook (gaz_engine_debug_fused_fault): workgroups with index % mod == 1 behave as if their wait had timed out
     // B0 (Gomoku, round 2): the FIRST block of the network — 256 stem channels -> 128 with a 1x1 projection on the skip path
     // (Net/ResNet/ResNet_Block.py:21-33) — runs inside this launch too, ahead of blocks 1..: x0 = raw stem output [M][256];
     // w then starts with block 0's 29 slices (conv1 channels 0-127 | 128-255, conv2, projection low | high); prm0 [1024] =
@@ -180,12 +186,33 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         const int row = lrow[tm], cslot = (wn * TN + tn) * 4 + j;
         return row * 256 + (swz_slot<M16>(cslot, row) << 4) + lhi * 8;
     };
-    if (STEM && a.ready) {                          // wait for the tree teams of this tile's boards (see TrunkArgs::ready)
+    // fused launch: "this workgroup's wait ran out", workgroup-uniform after the barrier.  A word of the idle parameter set (free until block 0
+    // stages the next block's vectors): a static __shared__ variable would move the dynamic segment off its 256-byte boundary (ldsb check below)
+    volatile int& gave_up = *reinterpret_cast<volatile int*>(Ps + TR_PRM + 256);
+    if (STEM && a.ready) {                          // wait for the tree teams of this tile's boards (see TrunkArgs::ready), for a bounded time
+        if (tid == 0) gave_up = 0;                  // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
         const long b = m0 / HW + tid;
-        if (tid < tile_rows / HW && b * HW < a.M)
-            while ((int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) __builtin_amdgcn_s_sleep(16);
+        if (tid < tile_rows / HW && b * HW < a.M) {
+            bool fail = a.test_fault_mod && blockIdx.x % a.test_fault_mod == 1;
+            if (!fail && (int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
+                const unsigned long long t0 = wall_clock64();
+                fail = a.fuse_fault && __hip_atomic_load(a.fuse_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                while (!fail && (int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
+                    __builtin_amdgcn_s_sleep(16);
+                    fail = wall_clock64() - t0 > (unsigned long long)a.spin_ticks;
+                }
+            }
+            if (fail) gave_up = 1;
+        }
+        asm volatile("" ::: "memory");              // no plane load may be hoisted above the poll
     }
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
+    if (STEM && a.ready && __builtin_amdgcn_readfirstlane(gave_up)) {   // (scalar branch) leave the tile out: every board of it is marked, the tree re-requests (DevParams::eval_skipped)
+        const long b = m0 / HW + tid;
+        if (tid < tile_rows / HW && b * HW < a.M && a.skipped) __hip_atomic_store(a.skipped + b, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
+        return;
+    }
     TR_STAMP(1);
 
     f32x16 acc[TM][TN];

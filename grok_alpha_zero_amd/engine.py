@@ -19,7 +19,7 @@ EVAL_HASH, EVAL_RESNET, EVAL_EXTERNAL = 0, 1, 2
 PH_WAIT_HOST, PH_HALT, PH_IDLE = 5, 8, 9
 
 
-ABI_VERSION = 2               # GAZ_ENGINE_ABI_VERSION of include/gaz_engine.h this binding was written against
+ABI_VERSION = 3               # GAZ_ENGINE_ABI_VERSION of include/gaz_engine.h this binding was written against
 
 
 class EngineConfig(C.Structure):       # gaz_engine_config — tests/test_abi.py checks names, order and sizeof against the header
@@ -94,6 +94,7 @@ def load_library(lib_path=None):
     L.gaz_engine_set_hyperparams.argtypes = [H, C.POINTER(SearchHyperparams)]
     L.gaz_engine_probe_rules.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.gaz_engine_set_fused_wave.argtypes = [H, C.c_int32]
+    L.gaz_engine_debug_fused_fault.argtypes = [H, C.c_int32]
     L.gaz_engine_repack.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_read_head_features.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
@@ -102,7 +103,7 @@ def load_library(lib_path=None):
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
               "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search",
-              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave", "repack"):
+              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave", "debug_fused_fault", "repack"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -297,7 +298,7 @@ class SelfPlayEngine:
         out = (C.c_uint64 * 16)()
         self._ck(self.L.gaz_engine_get_stats(self.h, out))
         s = [int(x) for x in out]
-        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11], fused_wave=s[12])
+        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11], fused_wave=s[12], fused_faults=s[13])
 
     def drain_finished(self, max_records=None):
         """Finished games as dicts: actions, policies [T,A], q, z, values (=0.5(z+q), Self_Play.py:165-172),
@@ -343,6 +344,10 @@ class SelfPlayEngine:
     def set_fused_wave(self, on=True):
         """tree step + trunk kernel as one launch (default where available) or as separate launches; results do not change"""
         self._ck(self.L.gaz_engine_set_fused_wave(self.h, int(bool(on))))
+
+    def debug_fused_fault(self, mod):
+        """TEST HOOK: trunk workgroups with index % mod == 1 of the following fused launches give up their wait at once (0 = off)"""
+        self._ck(self.L.gaz_engine_debug_fused_fault(self.h, int(mod)))
 
     def timing_reset(self, enable=True):
         self._ck(self.L.gaz_engine_timing_reset(self.h, int(enable)))

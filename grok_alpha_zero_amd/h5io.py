@@ -62,6 +62,7 @@ def _lib():
         ("H5Lexists", C.c_int, [hid_t, C.c_char_p, hid_t]), ("H5Fflush", C.c_int, [hid_t, C.c_int]),
         ("H5Lget_name_by_idx", C.c_ssize_t, [hid_t, C.c_char_p, C.c_int, C.c_int, hsize_t, C.c_char_p, C.c_size_t, hid_t]),
         ("H5Pset", C.c_int, [hid_t, C.c_char_p, C.c_void_p]), ("H5Ldelete", C.c_int, [hid_t, C.c_char_p, hid_t]),
+        ("H5Eget_auto2", C.c_int, [hid_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ]:
         fn = getattr(L, f); fn.restype = res; fn.argtypes = args
     _LIB = L
@@ -70,6 +71,34 @@ def _lib():
 
 def _g(name):
     return hid_t.in_dll(_lib(), name).value
+
+
+class _quiet:
+    """libhdf5's automatic error printing switched off for the calls inside the block only (a failure there is reported through an OSError
+    or is an expected probe); the process-wide handler is put back afterwards, so other users of libhdf5 keep their diagnostics."""
+
+    def __enter__(self):
+        L = _lib()
+        self.func, self.data = C.c_void_p(), C.c_void_p()
+        L.H5Eget_auto2(0, C.byref(self.func), C.byref(self.data))
+        L.H5Eset_auto2(0, None, None)
+
+    def __exit__(self, *a):
+        _lib().H5Eset_auto2(0, self.func, self.data)
+        return False
+
+
+def superblock_status_flags(path):
+    """The "file consistency flags" byte of an HDF5 version 2 / 3 superblock at offset 0 (bit 0: open for write, bit 2: SWMR write) — set
+    while a writer has the file open and left set by a writer that was killed; None when the file has no such superblock."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(12)
+    except OSError:
+        return None
+    if len(head) < 12 or head[:8] != b"\x89HDF\r\n\x1a\n" or head[8] < 2:
+        return None
+    return head[11]
 
 
 _FILE_TYPES = {np.dtype(np.int8): "H5T_STD_I8LE_g", np.dtype(np.uint8): "H5T_STD_U8LE_g", np.dtype(np.int32): "H5T_STD_I32LE_g",
@@ -94,11 +123,11 @@ class H5File:
             if L.H5Pset(fapl, b"clear_status_flags", C.byref(one)) < 0:
                 L.H5Pclose(fapl)
                 raise OSError("this libhdf5 has no clear_status_flags file-access property")
-        L.H5Eset_auto2(0, None, None)                              # failures are reported through the OSError below, not on stderr
-        if mode == "w":
-            self.fid = L.H5Fcreate(path.encode(), 2, 0, fapl)      # H5F_ACC_TRUNC
-        else:
-            self.fid = L.H5Fopen(path.encode(), 1 if mode == "r+" else 0, fapl)
+        with _quiet():                                             # failures are reported through the OSError below, not on stderr
+            if mode == "w":
+                self.fid = L.H5Fcreate(path.encode(), 2, 0, fapl)  # H5F_ACC_TRUNC
+            else:
+                self.fid = L.H5Fopen(path.encode(), 1 if mode == "r+" else 0, fapl)
         L.H5Pclose(fapl)
         if self.fid < 0:
             raise OSError(f"cannot open {path} (mode {mode})")
@@ -146,7 +175,6 @@ class H5File:
     def walk(self, group=""):
         """paths of every dataset below `group`, in link-name order (groups are told from datasets by trying to open them)"""
         L = _lib()
-        L.H5Eset_auto2(0, None, None)                              # probing a dataset with H5Gopen2 is expected to fail quietly
         out = []
 
         def rec(gid, prefix):
@@ -164,14 +192,15 @@ class H5File:
                 else:
                     out.append(prefix + name)
 
-        if group:
-            gid = L.H5Gopen2(self.fid, group.encode(), 0)
-            if gid < 0:
-                raise KeyError(group)
-            rec(gid, group.rstrip("/") + "/")
-            L.H5Gclose(gid)
-        else:
-            rec(self.fid, "")
+        with _quiet():                                             # probing a dataset with H5Gopen2 is expected to fail quietly
+            if group:
+                gid = L.H5Gopen2(self.fid, group.encode(), 0)
+                if gid < 0:
+                    raise KeyError(group)
+                rec(gid, group.rstrip("/") + "/")
+                L.H5Gclose(gid)
+            else:
+                rec(self.fid, "")
         return out
 
     def create_dataset(self, name, data, maxshape=None, dtype=None):

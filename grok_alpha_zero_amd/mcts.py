@@ -180,10 +180,10 @@ class MCTS_Gumbel(_EngineSearch):
 
     def update_hyperparams(self, *args, **kwargs):                                       # MCTS_Gumbel.py:186-210
         upd = {k: kwargs[k] for k in ("m", "c_visit", "c_scale") if kwargs.get(k) is not None}
+        if upd:
+            self._eng.set_hyperparams(**upd)        # validates first (m >= 2, m / iterations within the node arena): a refused update leaves self untouched
         for k, v in upd.items():
             setattr(self, k, v)
-        if upd:
-            self._eng.set_hyperparams(**upd)
 
     def run(self, iteration_limit=None, time_limit=None, use_bar=True):
         """-> (move, rows); row = [action, pi, mean value (pi where unvisited), W, N, logit, root.visits, is_terminal] sorted by pi."""

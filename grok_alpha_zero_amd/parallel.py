@@ -45,17 +45,20 @@ def run_self_play_sharded(game_class, configs, folder_path, *, n_games=1024, see
     rank, world = dist.get_rank(), dist.get_world_size()
     train_config = dict(configs[1])
     main = ReplayStore(folder_path)
-    left = np.zeros(4, np.int64)                                       # [games missing, games done, seed low 31 bits, seed high 31 bits]
+    left = np.zeros(5, np.int64)                                       # [games missing, games done, the 64-bit seed in three 22-bit limbs]
     if rank == 0:
         if not main.exists():
             raise ValueError("Dataset file hasn't been created. Self play depends on that file!")
+        main.recover()                                                 # rank 0 is the merged file's single writer
         done = int(main.game_stats()[2])
         left[0] = max(0, int(train_config["games_per_generation"]) - done); left[1] = done
-        s0 = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
-        left[2] = s0 & 0x7FFFFFFF; left[3] = (s0 >> 31) & 0x7FFFFFFF
+        s0 = (int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+        # every bit of the engine's 64-bit seed travels (limbs small enough for any integer reduction): a sharded run and a single-GPU run
+        # given the same explicit seed use the same RNG streams
+        left[2] = s0 & 0x3FFFFF; left[3] = (s0 >> 22) & 0x3FFFFF; left[4] = s0 >> 44
     left = reduce_stats(left, world)                                   # ranks > 0 contribute zeros: a broadcast through the one collective
     games_left, games_done = int(left[0]), int(left[1])
-    seed = int(left[2]) | (int(left[3]) << 31)
+    seed = int(left[2]) | (int(left[3]) << 22) | (int(left[4]) << 44)
     share = games_left // world + (1 if rank < games_left % world else 0)
     generation = int(str(folder_path).rstrip("/").split("/")[-1])
     shard_dir = os.path.join(folder_path, f".shard{rank}")

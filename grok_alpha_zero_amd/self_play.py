@@ -60,7 +60,7 @@ class ReplayStore:
     def n_datasets(self):
         if self.backend == "npy":
             return len([n for n in os.listdir(self.path) if n != "game_stats.npy"])
-        with self._open_checked("r") as f:
+        with self._open_read() as f:
             return f.n_links() - 1
 
     # A generation appends thousands of games.  Opening the file and counting its datasets per game made the writer, not the GPU,
@@ -68,27 +68,50 @@ class ReplayStore:
     # superblock's write flag set when the process was killed, and the file could not be reopened.  So `writing()` BUFFERS games and
     # writes them in batches — open, append `flush_every` games, close: the file is open for write only for the milliseconds of a
     # batch (the reference's exposure is one game's write, Self_Play.py:178-208), and a killed run keeps every batch it completed.
-    def _open_checked(self, mode):
-        """Open for "r" / "r+"; a file left "open for write" by a killed writer (libhdf5 then refuses every open) is repaired first
-        by clearing its status flags — what `h5clear -s` does."""
+    def recover(self):
+        """Repair a file that a KILLED writer left "open for write" (libhdf5 then refuses every open): clear the superblock's status flags, what
+        `h5clear -s` does.  Only for the generation's single writer (run_self_play calls it before it reads the counters); a reader never
+        repairs — the flag is also what a LIVE writer's open file looks like.  Returns True if a repair was made; any other reason for the
+        file not opening is raised as it is."""
+        if self.backend != "libhdf5" or not os.path.exists(self.path):
+            return False
         try:
-            return self._open(mode)
-        except OSError:
-            if self.backend != "libhdf5" or not os.path.exists(self.path):
+            self._open("r").close()
+            return False
+        except OSError as first:
+            from .h5io import H5File, superblock_status_flags
+            flags = superblock_status_flags(self.path)
+            if not flags:                                             # not the interrupted-writer case: permissions, truncation, not HDF5 ...
                 raise
-            from .h5io import H5File
             f = H5File(self.path, "r+", clear_status_flags=True)
             try:
                 ok = f.n_links() >= 1 and f.read("game_stats").shape == (6,)      # must still be readable, else beyond this repair
             finally:
                 f.close()
             if not ok:
-                raise OSError(f"{self.path}: left inconsistent by an interrupted writer")
-            logging.getLogger("grok_alpha_zero_amd").warning("%s was left open by an interrupted writer; status flags cleared", self.path)
-            return self._open(mode)
+                raise OSError(f"{self.path}: left inconsistent by an interrupted writer") from first
+            logging.getLogger("grok_alpha_zero_amd").warning("%s was left open (status flags %#x) by an interrupted writer; flags cleared", self.path, flags)
+            return True
+
+    def _open_read(self):
+        try:
+            return self._open("r")
+        except OSError as e:
+            if self.backend == "libhdf5":
+                from .h5io import superblock_status_flags
+                if superblock_status_flags(self.path):
+                    raise OSError(f"{self.path} is marked open for write: a writer is running, or one was killed — in that case the generation's "
+                                  "writer repairs it (ReplayStore.recover(), which run_self_play calls); readers do not") from e
+            raise
 
     def _open_rw(self):
-        return self._open_checked("r+")
+        """the single writer's open: repairs after a killed predecessor"""
+        try:
+            return self._open("r+")
+        except OSError:
+            if not self.recover():
+                raise
+            return self._open("r+")
 
     def writing(self, flush_every=64, flush_bytes=64 << 20):
         store = self
@@ -127,10 +150,15 @@ class ReplayStore:
             for kind, payload in buf:
                 if kind == "stats":
                     stats = payload.copy()
+                    f.write("game_stats", stats)
                     continue
                 if kind == "game":
                     boards_aug, policies_aug, values_aug, game_length, n_positions, winner = payload
                     stats[0] = max(int(stats[0]), game_length); stats[1] += n_positions; stats[2] += 1; stats[winner + 4] += 1
+                    # the counters BEFORE the game's datasets, as the reference does (Self_Play.py:181-188 precede :190-208): a writer killed
+                    # inside a batch then never leaves games in the file that game_stats[2] does not count — run_self_play resumes from that
+                    # count (games_left, first_game_seq), and an under-count would replay the (slot, game_seq) streams of the uncounted games
+                    f.write("game_stats", stats)
                     triples = [(boards_aug[i], policies_aug[i], values_aug[i]) for i in range(policies_aug.shape[0])]
                 else:
                     triples = [payload]
@@ -139,7 +167,6 @@ class ReplayStore:
                     f.create_dataset(f"policies_{k}", p, maxshape=(None, *p.shape[1:]), dtype=np.float32)
                     f.create_dataset(f"values_{k}", v, maxshape=(None, *v.shape[1:]), dtype=np.float32)
                     k += 1
-            f.write("game_stats", stats)                              # last: a batch cut short leaves the count behind the data
         finally:
             f.close()
 
@@ -190,7 +217,7 @@ class ReplayStore:
     def read(self, name):
         if self.backend == "npy":
             return np.load(os.path.join(self.path, name + ".npy"))
-        with self._open_checked("r") as f:
+        with self._open_read() as f:
             return f.read(name)
 
 
@@ -311,6 +338,7 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
     store = ReplayStore(folder_path)
     if not store.exists():
         raise ValueError("Dataset file hasn't been created. Self play depends on that file!")     # Self_Play.py:264-265
+    store.recover()                                 # this process is the generation's single writer: repair what a killed predecessor left
     games_done = int(store.game_stats()[2])
     games_left = int(train_config["games_per_generation"] - games_done)
     if games_left <= 0:

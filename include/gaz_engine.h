@@ -28,6 +28,8 @@
  *   gaz_engine_stop_search        run(time_limit)                              MCTS.py:560-563
  *   gaz_engine_repack             finished workers no longer load the inference server  Self_Play.py:380-400
  *   gaz_engine_set_fused_wave     (scheduling switch; no reference counterpart: Client_Server.py's server loop is what it replaces)
+ *   gaz_engine_debug_fused_fault  (test hook for that launch's bounded hand-over; what it replaces is the client's unbounded
+ *                                  spin on the server's flag, Client_Server.py:42-55)
  *   gaz_engine_evaluate        sess.run on a stacked batch (evaluator probe)   Compute_Speed.py:40-63, Client_Server.py:199-206
  *   gaz_engine_read_head_features  intermediate tensors of that probe (numerics tests)  Connect4/Build_Model.py:41-47,62-66
  */
@@ -46,7 +48,7 @@ enum { GAZ_EVAL_HASH = 0,      /* synthetic bit-reproducible evaluator (parity t
        GAZ_EVAL_RESNET = 1,    /* the ResNet policy/value network, HIP MFMA kernels */
        GAZ_EVAL_EXTERNAL = 2   /* caller evaluates the batch between wave_begin / wave_end */ };
 
-#define GAZ_ENGINE_ABI_VERSION 2   /* bumped whenever gaz_engine_config / gaz_search_hyperparams / an entry point changes */
+#define GAZ_ENGINE_ABI_VERSION 3   /* bumped whenever gaz_engine_config / gaz_search_hyperparams / an entry point changes */
 
 typedef struct {
     uint32_t struct_size;         /* = sizeof(gaz_engine_config) of the header the caller was built against; gaz_engine_create
@@ -190,7 +192,9 @@ int gaz_engine_drain_finished(gaz_engine* h, void* out, int32_t max_records, int
 int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]);  /* [0..5] game_stats, [6] evaluator calls, [7] simulations,
                                                                [8] plies played (= positions, incl. games in progress), [9] waves launched,
                                                                [10] evaluations answered by the evaluation cache, [11] groups of the group pipeline (0 = off),
-                                                               [12] 1 = tree step and trunk kernel run as ONE fused launch */
+                                                               [12] 1 = tree step and trunk kernel run as ONE fused launch,
+                                                               [13] trunk workgroups of fused launches that gave up waiting for their games (see
+                                                                    gaz_engine_debug_fused_fault); non-zero = the engine has fallen back to separate launches */
 int gaz_engine_synchronize(gaz_engine* h);
 
 /* Connect4 PUCT with the ResNet evaluator runs the tree step and the trunk kernel of a wave as ONE launch (k_wave_trunk: the trunk
@@ -198,11 +202,22 @@ int gaz_engine_synchronize(gaz_engine* h);
  * for bit; bench.py uses it to time the trunk kernel on its own).  Scheduling only. */
 int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on);
 
+/* The fused launch hands leaf rows from tree blocks to trunk workgroups INSIDE one running kernel, which assumes that the tree blocks (lowest
+ * block indices) become resident before the trunk workgroups that wait for them — HIP promises no dispatch order.  The wait is therefore
+ * bounded (20 ms): a trunk workgroup that runs out of time leaves its boards unevaluated and marks them, the games keep their requests
+ * pending and are evaluated by the next wave (no result changes), and at its next synchronisation point the engine switches to separate
+ * launches for good (get_stats [13] counts the workgroups that gave up).  This hook makes every trunk workgroup with index % mod == 1 behave
+ * as if its wait had timed out (mod = 0: off), so that the recovery path can be tested where the assumption holds. */
+int gaz_engine_debug_fused_fault(gaz_engine* h, int32_t mod);
+
 /* Continuous self-play with a games_budget: towards the end of a generation more and more slots have played their last game, but a
  * wave still steps and evaluates every slot.  repack moves the games that still run into the lowest slots (tree arena slice, records,
  * pending evaluator rows; a game keeps its identity) and shrinks all later launches to them.  *n_active = games still running,
  * *n_launch = slots the launches cover from now on.  Results do not change.  (The reference's counterpart is simply that finished
- * worker processes stop asking the inference server, Self_Play.py:380-400.) */
+ * worker processes stop asking the inference server, Self_Play.py:380-400.)
+ * After a repack a PHYSICAL slot index no longer identifies a game (records carry the game's own slot id): gaz_engine_set_position and
+ * gaz_engine_reset_games with a slot list are refused from then on; gaz_engine_reset_games(h, NULL, 0) restarts every slot and makes the
+ * launches cover all of them again.  The batch-level calls (read_batch / write_outputs / get_root_stats) keep addressing physical rows. */
 int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */

@@ -243,3 +243,36 @@ def test_emu_repack_keeps_every_game_gumbel_and_compaction(emu_lib, oracle):
                 lambda s, q: oracle.selfplay_game_gumbel("Connect4", 16, 42, 4, 50.0, 1.0, 13, s, q, hash_salt=6))
     _repack_run(emu_lib, oracle, "Connect4", 10, 24, 16, 42, dict(compact_trees=1),
                 lambda s, q: oracle.selfplay_game("Connect4", 16, 42, 4, 3, 2.5, 0.5, 13, s, q, hash_salt=6))
+
+
+@pytest.mark.parametrize("search,cache", [("puct", 0), ("gumbel", 0), ("puct", 12)])
+def test_emu_skipped_evaluations_are_requested_again(emu_lib, oracle, search, cache):
+    """The recovery path of the fused launch's BOUNDED hand-over (trunk.hpp TrunkArgs::spin_ticks, DevParams::eval_skipped): a trunk workgroup
+    that gives up leaves its boards unevaluated and marks them.  gaz_engine_debug_fused_fault injects exactly that on this build (marks the
+    games, poisons their outputs with NaN, raises the fault counter): the marked games must keep their requests pending and be evaluated by the
+    next wave — finished games identical to the oracle's — and the host must count the faults at its next synchronisation point."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, SEARCH_GUMBEL, SEARCH_PUCT
+    G, iters = 12, 24
+    kw = dict(search=SEARCH_GUMBEL, gumbel_m=4, c_visit=50.0, c_scale=1.0) if search == "gumbel" else dict(search=SEARCH_PUCT)
+    eng = SelfPlayEngine("Connect4", G, iters, 42, 8, 7, 2.5, 0.5, seed=11, hash_salt=3, ring_capacity=64, games_budget=G, lib_path=emu_lib,
+                         eval_cache_log2=cache, **kw)
+    recs, faults = [], 0
+    for rnd in range(4000):
+        if rnd % 3 == 0 and rnd < 60:
+            eng.debug_fused_fault(2)                       # games 3..5, 9..11 lose the evaluations of the following waves, until the host notices
+        eng.run_waves(5)
+        st = eng.stats()                                   # a synchronisation point: faults seen, hook cleared
+        faults = st["fused_faults"]
+        recs += eng.drain_finished()
+        if len(recs) == G:
+            break
+    eng.close()
+    assert len(recs) == G and faults > 0, (len(recs), faults)
+    for r in recs:
+        if search == "gumbel":
+            o = oracle.selfplay_game_gumbel("Connect4", iters, 42, 4, 50.0, 1.0, 11, r["slot"], 0, hash_salt=3)
+        else:
+            o = oracle.selfplay_game("Connect4", iters, 42, 8, 7, 2.5, 0.5, 11, r["slot"], 0, hash_salt=3)
+        assert r["T"] == o["T"], r["slot"]
+        for k in ("actions", "root_N", "root_W", "policies", "values"):
+            np.testing.assert_array_equal(r[k], o[k], err_msg=f"slot {r['slot']} {k}")

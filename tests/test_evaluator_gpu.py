@@ -447,6 +447,43 @@ def test_fused_tree_and_trunk_launch_gives_identical_games():
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
 
 
+@pytest.mark.parametrize("cache", [0, 16])
+def test_fused_launch_bounded_wait_recovers_without_changing_games(cache):
+    """The fused launch's hand-over is bounded (trunk.hpp TrunkArgs::spin_ticks; ADVICE r2 / VERDICT r2 item 5): a trunk workgroup whose games'
+    tree block does not show up gives up, leaves its boards unevaluated and marks them; the games keep their requests pending, the next wave
+    evaluates them, and the host falls back to separate launches at its next synchronisation point.  gaz_engine_debug_fused_fault makes every
+    5th trunk workgroup of the REAL k_wave_trunk launches take that path (one wave in four of its games' evaluations is lost, for 48 launches in a
+    row): the finished games must equal those of an undisturbed engine bit for bit, and the engine must report the faults and the fallback."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=5).eval().export_engine_weights()
+    got = []
+    for fault in (True, False):
+        eng = SelfPlayEngine("Connect4", 1600, 24, 14, 4, 3, 2.5, 0.5, seed=23, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192, games_budget=1600,
+                             eval_cache_log2=cache)
+        eng.load_weights(w)
+        eng.run_waves(40); eng.synchronize()
+        assert eng.stats()["fused_wave"] == 1
+        if fault:
+            eng.debug_fused_fault(5)
+            eng.run_waves(48)                          # no host synchronisation in between: 48 fused launches with workgroups giving up
+            st = eng.stats()
+            assert st["fused_faults"] >= 48 and st["fused_wave"] == 0, st
+        for _ in range(40):
+            eng.run_waves(100)
+            got_now = eng.stats()
+            if got_now["game_stats"][2] >= 1600:
+                break
+        assert eng.stats()["fused_wave"] == (0 if fault else 1)
+        got.append({(r["slot"], r["game_seq"]): r for r in eng.drain_finished(8192)})
+        eng.close()
+    a, b = got
+    assert len(a) == 1600 and set(a) == set(b)
+    for k in a:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
+
+
 @pytest.mark.parametrize("blocks,active,n,b0", [(2, 1, 23, "1"), (2, -1, 9, "1"), (2, -1, 9, "0"), (10, 1, 12, "1"), (10, 5, 12, "1"), (10, 9, 33, "1"), (10, 9, 33, "0")])
 def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n, b0, monkeypatch):
     """The Gomoku network's kernels (k_stem_mfma; block 0 with its in-LDS pre-activation and the projection accumulated into conv2 —

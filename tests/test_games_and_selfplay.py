@@ -434,7 +434,17 @@ def test_replay_file_survives_a_hard_kill(tmp_path, mode):
     script = tmp_path / "kill_worker.py"; script.write_text(_KILL_WORKER)
     rc = subprocess.call([sys.executable, str(script), ROOT, folder, mode])
     assert rc == 9
-    gs = store.game_stats()                        # reading comes first in run_self_play (games_left): it must work after the kill too
+    if mode == "handle_open":
+        # a READER never repairs — the flag is also what a live writer's file looks like.  The generation's single writer
+        # does, explicitly (run_self_play calls recover() before it reads the counters), and only when the superblock flag really is set.
+        from grok_alpha_zero_amd.h5io import superblock_status_flags
+        assert superblock_status_flags(store.path)
+        with pytest.raises(OSError, match="marked open for write"):
+            store.game_stats()
+        assert superblock_status_flags(store.path)                  # still set: the failed read changed nothing
+        assert store.recover() is True and not superblock_status_flags(store.path)
+    assert store.recover() is False                # nothing (more) to repair
+    gs = store.game_stats()
     if mode == "between_batches":
         assert gs[2] == 3 and store.n_datasets() == 3 * 2 * 3 and [gs[3], gs[4], gs[5]] == [1, 1, 1]
     # resuming works either way: one more game goes in and the file stays readable
@@ -444,6 +454,42 @@ def test_replay_file_survives_a_hard_kill(tmp_path, mode):
     assert gs[2] == (4 if mode == "between_batches" else 1)
     k = store.n_datasets() // 3 - 1
     assert store.read(f"boards_{k}").shape == (4, 6, 7, 4)
+
+
+def test_writer_killed_inside_a_batch_never_leaves_uncounted_games(tmp_path, monkeypatch):
+    """_flush used to write game_stats LAST, after all datasets of a batch of up to 64 games; a writer killed inside the
+    batch left complete games in the file that game_stats[2] did not count, and a resumed run_self_play (games_left and first_game_seq come
+    from that count) generated too many games and, with a fixed seed, replayed the uncounted ones.  Now the counters go in BEFORE each game's
+    datasets, as in the reference (Self_Play.py:181-208): whatever the point of death, counted games >= games in the file."""
+    from grok_alpha_zero_amd import h5io
+    from grok_alpha_zero_amd.self_play import ReplayStore
+    folder = str(tmp_path / "Grok_Zero_Train" / "0")
+    store = ReplayStore(folder); store.create()
+    if store.backend != "libhdf5":
+        pytest.skip("needs the libhdf5 backend")
+    b = np.zeros((2, 5, 6, 7, 4), np.int8); p = np.full((2, 5, 7), 1 / 7, np.float32); v = np.zeros((2, 5, 1), np.float32)
+    for die_after in (0, 2, 6, 7, 11, 12, 17):                     # datasets created before the "kill": inside a triple, between triples, between games
+        n0 = store.n_datasets(); g0 = int(store.game_stats()[2])
+        calls = {"n": 0}
+        real = h5io.H5File.create_dataset
+
+        def dying(self, *a, **k):
+            if calls["n"] == die_after:
+                raise KeyboardInterrupt("killed")
+            calls["n"] += 1
+            return real(self, *a, **k)
+        monkeypatch.setattr(h5io.H5File, "create_dataset", dying)
+        with pytest.raises(KeyboardInterrupt):
+            with store.writing(flush_every=64):
+                for i in range(3):
+                    store.append_game(b + i, p, v, 5, 5, (-1, 0, 1)[i])
+        monkeypatch.setattr(h5io.H5File, "create_dataset", real)
+        store._buf = []                                            # the dead writer's memory is gone
+        counted = int(store.game_stats()[2]) - g0
+        complete_games = (store.n_datasets() - n0 + (n0 % 3)) // 6          # 2 augmentations x 3 datasets per game
+        assert counted >= complete_games and counted <= complete_games + 1, (die_after, counted, complete_games)
+        store.append_game(b + 9, p, v, 5, 5, 0)                    # the next writer drops an incomplete triple and carries on
+        assert store.n_datasets() % 3 == 0
 
 
 def test_run_self_play_refuses_unsupported_requests(tmp_path):
