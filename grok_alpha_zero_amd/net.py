@@ -408,6 +408,43 @@ class TicTacToeNet(nn.Module):
         return p, v
 
     @torch.no_grad()
+    def forward_engine_numerics(self, x):
+        """The TicTacToe network as the HIP kernels compute it (netops.hpp k_stem_generic / k_conv_direct / k_dense: fp32 weights, bf16
+        activations between layers, fp32 everywhere else; convolutions summed in float64 here) — see Connect4Net.forward_engine_numerics.
+        Rounding points: stem output x0 = bf16(gelu(.)) and, from the UNROUNDED value, a0 = bf16(relu(bn1(.))); per block h =
+        bf16(relu(bn2(conv1(a)))), block 0's skip path x = bf16(proj(x0) + bp), x = bf16(conv2(h) + b2 + x) and again from the unrounded sum
+        the next block's operand a = bf16(relu(bn1'(.))); the heads' 1x1 convolutions read the bf16 x and stay in fp32 from there on."""
+        bf = lambda t: t.float().to(torch.bfloat16).float()
+        B = x.shape[0]
+
+        def conv(a, w, pad):
+            return F.conv2d(a.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None, padding=pad).permute(0, 2, 3, 1)
+        s, t = self.stem_bn.affine()
+        v = F.gelu(conv(x.float(), self.stem.weight, 2).float() * s + (self.stem.bias * s + t))
+        xs = bf(v)
+        s1, t1 = self.blocks[0].bn1.affine()
+        a = bf(F.relu(v * s1 + t1))
+        for i, b in enumerate(self.blocks):
+            s2, t2 = b.bn2.affine()
+            h = bf(F.relu(conv(a, b.conv1.weight, 1).float() * s2 + (b.conv1.bias * s2 + t2)))
+            if b.proj is not None:
+                xs = bf(conv(xs, b.proj.weight, 0).float() + b.proj.bias)
+            v = (conv(h, b.conv2.weight, 1).float() + b.conv2.bias) + xs
+            xs = bf(v)
+            if i + 1 < len(self.blocks):
+                s1, t1 = self.blocks[i + 1].bn1.affine()
+                a = bf(F.relu(v * s1 + t1))
+        sp, tp = self.p_bn.affine(); sv, tv = self.v_bn.affine()
+        pf = (conv(xs, self.p_conv.weight, 0).float() * sp + (self.p_conv.bias * sp + tp)).reshape(B, -1)
+        vf = (conv(xs, self.v_conv.weight, 0).float() * sv + (self.v_conv.bias * sv + tv)).reshape(B, -1)
+        d = lambda y, layer: (y.double() @ layer.weight.double() + layer.bias.double()).float()
+        logits = d(d(F.relu(d(pf, self.p_d1)), self.p_d2), self.p_d3)
+        vpre = d(F.relu(d(d(vf, self.v_d1), self.v_d2)), self.v_d3).reshape(-1)
+        out = dict(p_feat=pf, v_feat=vf, logits=logits, v_pre=vpre, value=torch.tanh(vpre))
+        out["policy"] = torch.softmax(logits, -1) if self.policy_head == "softmax" else (stablemax(logits) if self.policy_head == "stablemax" else logits)
+        return {k: v.numpy() for k, v in out.items()}
+
+    @torch.no_grad()
     def export_engine_weights(self):
         o = {}
         s, t = self.stem_bn.affine()

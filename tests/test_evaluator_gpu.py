@@ -536,3 +536,40 @@ def test_gomoku_evaluator_matches_bf16_faithful_reference_per_layer(blocks, acti
     else:
         assert m["p_feat_rel_max"] <= 8e-2 and m["v_feat_rel_max"] <= 8e-2 and m["p_feat_mean"] <= 2.5e-3 and m["v_feat_mean"] <= 2.5e-3, m
         assert m["logits_max"] <= 4e-2 and m["vpre_max"] <= 3e-2 and m["prob_max"] <= 5e-3 and m["value_max"] <= 1e-2, m
+
+
+@pytest.mark.parametrize("blocks,active,n", [(2, 0, 300), (2, 1, 300), (3, 2, 77), (3, -1, 9)])
+def test_tictactoe_evaluator_matches_bf16_faithful_reference_per_layer(blocks, active, n):
+    """the TicTacToe network (5x5 stem 2 -> 128, block 0 projecting 128 -> 64; netops.hpp k_stem_generic / k_conv_direct /
+    k_dense) had only the 6e-2 fp32 comparison.  Same scheme as the Connect4 and Gomoku launches: TicTacToeNet.forward_engine_numerics rounds to
+    bf16 exactly where the kernels do, and ONE residual block is active at a time (block 0's projection is always live — it is the skip path —
+    the other blocks have zero convolution weights and conv2 bias and pass the stream through bit for bit); active = -1: only the projection."""
+    import torch
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import TicTacToeNet
+    rng = np.random.default_rng(blocks * 100 + n + active)
+    x = np.zeros((n, 3, 3, 2), np.int8)
+    who = rng.integers(0, 3, size=(n, 3, 3))
+    x[..., 0] = who == 1; x[..., 1] = who == 2
+    for head, logits_mode in (("linear", 1), ("softmax", 0)):
+        net = TicTacToeNet(blocks, seed=4, policy_head=head).eval().randomize_bn(9)
+        with torch.no_grad():
+            for i, b in enumerate(net.blocks):
+                if i != active:
+                    b.conv1.weight.zero_(); b.conv2.weight.zero_(); b.conv2.bias.zero_()
+        eng = SelfPlayEngine("TicTacToe", max(n, 64), 50, 9, 2, 2, 2.5, 1.0, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks, net_filters=64,
+                             ring_capacity=0, policy_is_logits=logits_mode)
+        eng.load_weights(net.export_engine_weights())
+        pol, val, _ = eng.evaluate(x)
+        pf, vf = eng.head_features(n)
+        eng.close()
+        ref = net.forward_engine_numerics(torch.from_numpy(x))
+        m = {}
+        for name, got, want in (("p_feat", pf, ref["p_feat"]), ("v_feat", vf, ref["v_feat"])):
+            d = np.abs(got - want)
+            m[name + "_rel_max"] = float((d / np.maximum(np.abs(want), 1.0)).max()); m[name + "_mean"] = float(d.mean())
+        m["value_max"] = float(np.abs(val - ref["value"]).max())
+        m["pol_max"] = float(np.abs(pol - ref["policy"]).max())
+        print("tictactoe faithful metrics", blocks, active, head, m)
+        assert m["p_feat_rel_max"] <= 1e-2 and m["v_feat_rel_max"] <= 1e-2 and m["p_feat_mean"] <= 2e-4 and m["v_feat_mean"] <= 2e-4, m
+        assert m["pol_max"] <= (2e-3 if logits_mode else 1e-3) and m["value_max"] <= 1e-3, m
