@@ -245,14 +245,15 @@ def random_histories(game, n, rng, max_ply):
     for _ in range(n):
         want = int(rng.integers(0, max_ply + 1))
         while True:
-            g = cls(); hist = []
+            g = cls(); hist = []; over = False
             for _ply in range(want):
                 legal = g.get_legal_actions()
                 a = legal[int(rng.integers(0, len(legal)))]
-                g.do_action(a); hist.append(cls.action_to_index(a))
-                if g.check_win() != -2:
+                g.do_action(a); hist.append(int(cls.action_to_index(a)))
+                if g.check_win() != -2:                    # (check_win looks at the last action: never called on an empty board)
+                    over = True
                     break
-            if g.check_win() == -2:
+            if not over:
                 break
         out.append(hist)
     return out

@@ -181,7 +181,7 @@ template <class G> GAZ_KERNEL_WIDE k_move_slots(DevParams<G> E, const int32_t* m
     copy1(E.nn_in + (size_t)dst * (G::HW * G::C), E.nn_in + (size_t)src * (G::HW * G::C), G::HW * G::C);
     copy1(E.nn_policy + (size_t)dst * G::A, E.nn_policy + (size_t)src * G::A, 4 * G::A);
     copy1(E.nn_value + dst, E.nn_value + src, 4);
-    if (E.eval_skipped) copy1(E.eval_skipped + dst, E.eval_skipped + src, 4);
+    if (E.eval_done) copy1(E.eval_done + dst, E.eval_done + src, 4);
     // swap the two GameStates word by word (each thread its own words: no staging needed)
     uint32_t* ga = reinterpret_cast<uint32_t*>(&E.games[src]); uint32_t* gb = reinterpret_cast<uint32_t*>(&E.games[dst]);
     for (size_t i = t; i < sizeof(GameState<G>) / 4; i += T) { const uint32_t x = ga[i]; ga[i] = gb[i]; gb[i] = x; }
@@ -190,13 +190,13 @@ template <class G> GAZ_KERNEL_WIDE k_move_slots(DevParams<G> E, const int32_t* m
 // gaz_engine_debug_fused_fault on a path without the fused launch (other games / searches / the CPU emulation build): what a trunk workgroup
 // that gave up leaves behind — its boards marked with the wave's epoch, their outputs NOT those of this wave's requests (poisoned here, so that
 // a tree step that consumed them could not go unnoticed), the fault counter raised.
-template <class G> GAZ_KERNEL k_debug_skip(DevParams<G> E, int n, unsigned mod, int32_t* fault) {
+template <class G> GAZ_KERNEL k_debug_skip(DevParams<G> E, uint32_t* eval_done, int n, unsigned mod, int32_t* fault) {
     const int g = block_id();
-    if (g >= n || lane_id() != 0 || !E.eval_skipped || (unsigned)(g / 3) % mod != 1u) return;
-    E.eval_skipped[g] = E.wave_epoch;
+    if (g >= n || lane_id() != 0) return;
+    if ((unsigned)(g / 3) % mod != 1u) { eval_done[g] = E.wave_epoch; return; }      // evaluated this wave
     for (int a = 0; a < G::A; ++a) E.nn_policy[(size_t)g * G::A + a] = __builtin_nanf("");
     E.nn_value[g] = __builtin_nanf("");
-    if (g % 3 == 0 || g == 0) atomic_add(fault, (int32_t)1);
+    if (g % 3 == 0) atomic_add(fault, (int32_t)1);
 }
 
 template <class G> GAZ_KERNEL k_release(DevParams<G> E, const int32_t* moves) {
@@ -455,9 +455,11 @@ template <class G> struct EngineT : gaz_engine {
     hipEvent_t new_event() { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); return e; }
     static constexpr size_t MAX_TIMING_EVENTS = 1 << 16;            // a timed run of any length holds at most this many events
 
-    // every tree launch carries the wave's epoch once a fused launch may have left rows out (DevParams::eval_skipped)
-    DevParams<G> wave_params() { DevParams<G> P = E; if (E.eval_skipped) P.wave_epoch = ++fuse_epoch; return P; }
-    void launch_wave(hipStream_t st, int g0, int g1) { launch_wave(st, g0, g1, wave_params()); }
+    // every tree launch carries the wave's epoch, and the marks of the previous wave's evaluator pass if that pass made any (a fused launch, or
+    // the test hook): DevParams::eval_done
+    bool prev_marked = false;                        // the wave before this one wrote eval_done
+    DevParams<G> wave_params() { DevParams<G> P = E; P.wave_epoch = ++fuse_epoch; P.eval_done = prev_marked ? d_evaldone : nullptr; return P; }
+    void launch_wave(hipStream_t st, int g0, int g1) { const DevParams<G> P = wave_params(); prev_marked = false; launch_wave(st, g0, g1, P); }   // (callers follow with a full evaluator pass)
     void launch_wave(hipStream_t st, int g0, int g1, const DevParams<G>& E) {
         // the small boards run four games per wavefront (PuctVariant: same records, 16-lane teams); GAZ_TREE_TEAMS=0 -> one per wave
         typedef typename PuctVariant<G>::type GP;
@@ -483,10 +485,10 @@ template <class G> struct EngineT : gaz_engine {
     // ---- fused tree + trunk launch (resnet.hip k_wave_trunk): Connect4 PUCT with the whole-trunk ResNet evaluator, no evaluation
     // cache (its probe reads rows other teams are writing).  GAZ_FUSE_WAVE=0 -> separate launches.
     // The hand-over inside the launch is BOUNDED (trunk.hpp TrunkArgs::spin_ticks): HIP promises no dispatch order, so a trunk workgroup whose
-    // games' tree block is not resident may not wait forever.  A workgroup that gives up marks its boards in d_skipped and counts itself in
-    // d_fault; the games keep their requests pending (no result changes), and poll_fuse_fault() — at every host synchronisation point —
-    // switches this engine to separate launches for good.
-    uint32_t* d_done = nullptr; uint32_t* d_skipped = nullptr; int32_t* d_fault = nullptr;
+    // games' tree block is not resident may not wait forever.  A workgroup that gives up counts itself in d_fault and — unlike the others —
+    // does not mark its boards in d_evaldone; their games keep their requests pending (no result changes), and poll_fuse_fault() — at every host
+    // synchronisation point — switches this engine to separate launches for good.
+    uint32_t* d_done = nullptr; uint32_t* d_evaldone = nullptr; int32_t* d_fault = nullptr;
     uint32_t fuse_epoch = 0; int fuse_state = -1;     // -1 not decided, 0 off, 1 on
     uint64_t fuse_faults = 0;                        // trunk workgroups that gave up waiting, over the engine's life (get_stats [13])
     unsigned debug_fault_mod = 0;                    // test hook: gaz_engine_debug_fused_fault
@@ -521,9 +523,8 @@ template <class G> struct EngineT : gaz_engine {
     bool fuse_enabled = true;
     int set_fused_wave(int on) override { fuse_enabled = on != 0; return 0; }
     bool ensure_skip_buffers() {
-        if (d_skipped) return true;
-        if (dalloc(&d_skipped, (size_t)E.n_games) || dalloc(&d_fault, 4)) return false;
-        E.eval_skipped = d_skipped;
+        if (d_evaldone) return true;
+        if (dalloc(&d_evaldone, (size_t)E.n_games) || dalloc(&d_fault, 4)) return false;
         return true;
     }
     int debug_fused_fault(int mod) override {
@@ -565,9 +566,11 @@ template <class G> struct EngineT : gaz_engine {
             const size_t slot_bytes = (size_t)2 * (E.compact ? 2 : 1) * (size_t)E.nodes_per_tree * (size_t)E.node_bytes;
             const size_t gbytes = cfg.search == GAZ_SEARCH_GUMBEL ? sizeof(GumbelState<G>) : 0;
 #ifdef GAZ_HOST_EMU
-            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 1, stream, E, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
+            DevParams<G> Em = E; Em.eval_done = d_evaldone;              // a game's "evaluated last wave" mark travels with it
+            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 1, stream, Em, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
 #else
-            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 256, stream, E, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
+            DevParams<G> Em = E; Em.eval_done = d_evaldone;              // a game's "evaluated last wave" mark travels with it
+            GAZ_LAUNCH(k_move_slots<G>, (int)(mv.size() / 2), 256, stream, Em, (const int32_t*)dMoveList, (int)(mv.size() / 2), slot_bytes, gbytes);
 #endif
             HIP_OK(hipGetLastError());
             HIP_OK(hipStreamSynchronize(stream));
@@ -580,16 +583,17 @@ template <class G> struct EngineT : gaz_engine {
     int one_wave(bool with_eval) {
         if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
-            const FuseHandoff ho{d_done, fuse_epoch + 1, d_skipped, d_fault, SPIN_TICKS, debug_fault_mod};
+            const FuseHandoff ho{d_done, fuse_epoch + 1, d_evaldone, d_fault, SPIN_TICKS, debug_fault_mod};
             const void* plan = eval->trunk_plan(E.nn_in, n_eff, 0, ho);
             if (plan) {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
                 if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
-                DevParams<G> Ef = E; Ef.done_flag = d_done; Ef.wave_epoch = ++fuse_epoch;
+                DevParams<G> Ef = wave_params(); Ef.done_flag = d_done;
                 launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
+                prev_marked = true;                  // the trunk workgroups of this launch mark the boards they evaluate
                 if (timing) hipEventRecord(e1, stream);
                 eval->forward_heads(stream, E.nn_policy, E.nn_value, n_eff, 0);
-                if (E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, Ef, 0, n_eff); E.cache_epoch++; }
+                if (E.cache) { Ef.eval_done = d_evaldone; GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, Ef, 0, n_eff); E.cache_epoch++; }
                 if (timing) {       // the fused kernel is booked as evaluator time; tree time is what it hides
                     hipEventRecord(e2, stream); ev_eval.push_back({e0, e2}); n_waves_timed++;
                     ev_fused.push_back({e0, e1});
@@ -603,12 +607,17 @@ template <class G> struct EngineT : gaz_engine {
         const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
         hipEvent_t e0 = 0, e1 = 0, e2 = 0;
         if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
-        const DevParams<G> P = wave_params();
+        DevParams<G> P = wave_params();
         launch_wave(stream, 0, n_eff, P);
+        prev_marked = false;                         // the separately launched evaluator pass covers every row
         if (timing) hipEventRecord(e1, stream);
         if (with_eval && eval) eval->forward(stream, E.nn_in, E.nn_policy, E.nn_value, n_eff, timing);
         if (timing) { hipEventRecord(e2, stream); ev_tree.push_back({e0, e1}); ev_eval.push_back({e1, e2}); n_waves_timed++; }
-        if (with_eval && eval && debug_fault_mod && E.eval_skipped) GAZ_LAUNCH(k_debug_skip<G>, n_eff, WAVE, stream, P, n_eff, debug_fault_mod, d_fault);
+        P.eval_done = nullptr;
+        if (with_eval && eval && debug_fault_mod && d_evaldone) {      // test hook: this wave behaves as a fused launch with workgroups that gave up
+            GAZ_LAUNCH(k_debug_skip<G>, n_eff, WAVE, stream, P, d_evaldone, n_eff, debug_fault_mod, d_fault);
+            prev_marked = true; P.eval_done = d_evaldone;
+        }
         if (with_eval && eval && E.cache) { GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, P, 0, n_eff); E.cache_epoch++; }
         n_waves_total++;
         return 0;
@@ -660,7 +669,7 @@ template <class G> struct EngineT : gaz_engine {
         for (int k = 0; k < n; ++k) {
             const int cur = k & 1, prev = cur ^ 1;
             const bool timed = timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 2 * (size_t)n_grp <= MAX_TIMING_EVENTS;
-            const DevParams<G> P = wave_params();                         // one epoch per wave, whatever the number of groups
+            const DevParams<G> P = wave_params(); prev_marked = false;    // one epoch per wave, whatever the number of groups
             for (int g = 0; g < n_grp; ++g) {
                 const int g0 = grp0[g], g1 = grp0[g + 1];
                 if (k > 0) hipStreamWaitEvent(tstream, ev_heads_done[prev][g], 0);      // this group's previous evaluation

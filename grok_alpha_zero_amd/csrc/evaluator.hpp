@@ -13,7 +13,7 @@
 namespace gaz {
 
 // what a fused tree + trunk launch hands from the tree teams to the trunk workgroups (trunk.hpp TrunkArgs::ready ... test_fault_mod)
-struct FuseHandoff { const unsigned* ready; unsigned epoch; unsigned* skipped; int* fuse_fault; unsigned spin_ticks; unsigned test_fault_mod; };
+struct FuseHandoff { const unsigned* ready; unsigned epoch; unsigned* eval_done; int* fuse_fault; unsigned spin_ticks; unsigned test_fault_mod; };
 
 struct Evaluator {
     virtual ~Evaluator() {}

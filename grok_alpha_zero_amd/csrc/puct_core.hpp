@@ -75,10 +75,12 @@ template <class G> struct DevParams {
     // workgroups of the SAME launch can start on their boards while slower games are still searching.  Null = plain launches.
     uint32_t* done_flag;       // [n_games] epoch of the last launch that finished the game's tree step
     uint32_t wave_epoch;
-    // bounded hand-over (trunk.hpp TrunkArgs::skipped): a trunk workgroup whose wait for done_flag ran out of time leaves its boards unevaluated and
-    // writes the launch's epoch here; the game's next tree step then keeps its request pending (the leaf row is still in nn_in) instead of
-    // consuming outputs that were never computed.  A game only loses a wave: its results cannot change.  Null = never fused.
-    uint32_t* eval_skipped;    // [n_games]
+    // bounded hand-over (trunk.hpp TrunkArgs::eval_done): a trunk workgroup that takes its boards on writes the launch's epoch here; one whose
+    // wait for done_flag ran out of time leaves them unevaluated and writes nothing.  With eval_done set (= the PREVIOUS wave marked its rows), a
+    // game whose mark is not that wave's epoch keeps its request pending (the leaf row is still in nn_in) instead of consuming outputs that were
+    // never computed.  A game only loses a wave: its results cannot change.  (Marking success, not failure: a workgroup of THIS launch may give
+    // up before this game's team has even started, and must not be able to disturb what the team reads about the previous launch.)
+    uint32_t* eval_done;       // [n_games] or null
 };
 
 // stores / loads that meet at the device's point of coherence (no L1 / per-XCD L2 copy): used for the leaf rows and the done flags
@@ -559,7 +561,7 @@ template <class G> GAZ_DEV const uint8_t* cache_probe(const DevParams<G>& E, int
 template <class G> GAZ_DEV void cache_insert(const DevParams<G>& E, int g) {
     using CL = CacheLayout<G>;
     if (tuni<G>(E.games[g].pend_kind) == PEND_NONE) return;
-    if (E.eval_skipped && tuni<G>(E.eval_skipped[g]) == E.wave_epoch && E.wave_epoch) return;     // this wave's evaluator left the row out: nothing to store
+    if (E.eval_done && tuni<G>(E.eval_done[g]) != E.wave_epoch) return;     // this wave's evaluator left the row out: nothing to store
     const int8_t* row = E.nn_in + (size_t)g * CL::ROWB;
     const uint64_t h = mix64(row_hash<G>(row));
     const uint32_t slot = (uint32_t)h & E.cache_mask;
@@ -1073,10 +1075,10 @@ template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g) {
 #endif
 }
 
-// did the evaluator leave game g's row out in the previous wave (see DevParams::eval_skipped)?  Team-uniform.
+// did the evaluator leave game g's row out in the previous wave (see DevParams::eval_done)?  Team-uniform.
 template <class G> GAZ_DEV bool eval_was_skipped(const DevParams<G>& E, int g) {
-    if (!E.eval_skipped || E.wave_epoch < 2) return false;
-    return tuni<G>(E.eval_skipped[g]) == E.wave_epoch - 1;
+    if (!E.eval_done) return false;
+    return tuni<G>(E.eval_done[g]) != E.wave_epoch - 1;
 }
 
 template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {

@@ -477,7 +477,8 @@ struct ResNetEvaluator : Evaluator {
     bool trunk = true;                              // k_trunk: every block in one kernel (trunk.hpp); GAZ_TRUNK=0 -> one k_resblock3 per block
     bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;
     std::string dom_label;
-    uint8_t *perm_big = nullptr, *perm_small = nullptr;    // TrunkArgs::perm for the 128-row and the 96-row tile (tile_perm; GAZ_TILE_PERM=0: none)
+    uint8_t *perm_big = nullptr, *perm_small = nullptr;    // TrunkArgs::perm for the 128-row and the 96-row tile (tile_perm.hpp tile_layout; GAZ_TILE_PERM=0: none)
+    unsigned boff_big = 0, boff_small = 0; int perm_clashes = 0;      // TrunkArgs::boff; residue clashes the layout could not avoid (0: no LDS conflict in any fragment read)
     float *pfeat = nullptr, *vfeat = nullptr, *pd1 = nullptr, *vd1 = nullptr;
     std::vector<void*> allocs;
     bool loaded = false;
@@ -542,13 +543,15 @@ struct ResNetEvaluator : Evaluator {
         if (!(getenv("GAZ_TILE_PERM") && atoi(getenv("GAZ_TILE_PERM")) == 0) && !perm_big && 96 / HW >= 1) {
             // the kernels' static sit-out masks (trunk.hpp conv9): 128-row tile = two wave rows (y = 0 | x = 0) and (y = H - 1 | x = W - 1); 96-row
             // tile = one wave row (y = 0 | y = H - 1 | x = 0).  Both permutations must deliver exactly that, or neither is used.
-            const std::vector<uint8_t> pb = tile_perm(H, W, 128 / HW, 128, 64), ps = tile_perm(H, W, 96 / HW, 96, 96, 3);
-            const unsigned want_big[4] = {0x007u, 0x049u, 0x1C0u, 0x124u}, want_small[3] = {0x007u, 0x1C0u, 0x049u};
-            bool ok = !pb.empty() && !ps.empty();
-            for (int wr = 0; ok && wr < 2; ++wr) for (int t = 0; t < 2; ++t) ok = ok && (tile_sitout(pb, H, W, 128 / HW, wr * 4 + t) & want_big[wr * 2 + t]) == want_big[wr * 2 + t];
-            for (int t = 0; ok && t < 3; ++t) ok = (tile_sitout(ps, H, W, 96 / HW, t) & want_small[t]) == want_small[t];
-            if (ok && (perm_big = dalloc<uint8_t>(pb.size())) && (perm_small = dalloc<uint8_t>(ps.size()))) {
-                hipMemcpy(perm_big, pb.data(), pb.size(), hipMemcpyHostToDevice); hipMemcpy(perm_small, ps.data(), ps.size(), hipMemcpyHostToDevice);
+            unsigned want_big[8] = {0x007u, 0x049u, 0, 0, 0x1C0u, 0x124u, 0, 0}, want_small[6] = {0x007u, 0x1C0u, 0x049u, 0, 0, 0};
+            const TileLayout lb = tile_layout(H, W, 128 / HW, 128, 64, 2, want_big), ls = tile_layout(H, W, 96 / HW, 96, 96, 3, want_small);
+            const bool ok = !lb.perm.empty() && !ls.perm.empty() && lb.boff.size() <= 3 && ls.boff.size() <= 3;
+            if (ok && (perm_big = dalloc<uint8_t>(lb.perm.size())) && (perm_small = dalloc<uint8_t>(ls.perm.size()))) {
+                hipMemcpy(perm_big, lb.perm.data(), lb.perm.size(), hipMemcpyHostToDevice); hipMemcpy(perm_small, ls.perm.data(), ls.perm.size(), hipMemcpyHostToDevice);
+                boff_big = boff_small = 0;
+                for (size_t b = 0; b < lb.boff.size(); ++b) boff_big |= (unsigned)lb.boff[b] << (8 * b);
+                for (size_t b = 0; b < ls.boff.size(); ++b) boff_small |= (unsigned)ls.boff[b] << (8 * b);
+                perm_clashes = lb.clashes + ls.clashes;
             } else { perm_big = perm_small = nullptr; }
         }
         if (!up_b16("heads.conv.w", 9LL * 32 * Fc) || !up_f32("heads.conv.bias", 32)) return 1;
@@ -588,7 +591,7 @@ struct ResNetEvaluator : Evaluator {
         const int M = n * HW;
         TrunkArgs& r = P.args; memset(&r, 0, sizeof(r));
         r.xin = this->X + (size_t)p0 * HW * 128; r.xout = this->X2 + (size_t)p0 * HW * 128; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
-        r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small;
+        r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small; r.boff = boff_big; r.boff_small = boff_small;
         r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
         r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
         r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"];
@@ -608,7 +611,7 @@ struct ResNetEvaluator : Evaluator {
     const void* trunk_plan(const int8_t* in, int n, int p0, const FuseHandoff& h) override {
         if (!trunk_m16 || !make_trunk_plan(in, n, p0, fused_plan)) return nullptr;
         TrunkArgs& r = fused_plan.args;
-        r.ready = h.ready; r.epoch = h.epoch; r.skipped = h.skipped; r.fuse_fault = h.fuse_fault; r.spin_ticks = h.spin_ticks; r.test_fault_mod = h.test_fault_mod;
+        r.ready = h.ready; r.epoch = h.epoch; r.eval_done = h.eval_done; r.fuse_fault = h.fuse_fault; r.spin_ticks = h.spin_ticks; r.test_fault_mod = h.test_fault_mod;
         return &fused_plan;
     }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
@@ -644,7 +647,7 @@ struct ResNetEvaluator : Evaluator {
         bf16_t* cur = X;
         if (use_trunk) {                            // every block in one kernel, k whole boards per workgroup (trunk.hpp)
             TrunkArgs r; memset(&r, 0, sizeof(r)); r.xin = X; r.xout = X2; r.w = trunk_w; r.prm = trunk_prm; r.M = M; r.H = H; r.W = W; r.nblocks = blocks;
-            r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small;
+            r.tile_rows = (128 / HW) * HW; r.stamps = nullptr; r.perm = perm_big; r.perm_small = perm_small; r.boff = boff_big; r.boff_small = boff_small;
             r.planes = in; r.stem_frag = reinterpret_cast<const uint4*>(stem_frag); r.stem_shift = f32["stem.shift"];
             r.hw = b16["heads.conv.w"]; r.hbias = f32["heads.conv.bias"]; r.p_fs = f32["p.bn0.scale"]; r.p_ft = f32["p.bn0.shift"];
             r.v_fs = f32["v.bn0.scale"]; r.v_ft = f32["v.bn0.shift"]; r.p_feat = pfeat; r.v_feat = vfeat;
@@ -1223,8 +1226,8 @@ __device__ __forceinline__ void wave_trunk_body(const DevParams<GP>& E, int g0, 
     }
     // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid
     const int bid = (int)blockIdx.x - n_tree_blocks;
-    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr);
-    else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr);
+    if (MIX && bid >= a.n_big) trunk_tile<3, 4, 8, true, true, false, true, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)(bid - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr, a.boff_small);
+    else trunk_tile<2, 2, 8, true, true, false, true, 4, false, SKIP ? 1 : 0>(a, (long)bid * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr, a.boff);
 }
 
 template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {

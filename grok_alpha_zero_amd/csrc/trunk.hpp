@@ -36,9 +36,10 @@ struct TrunkArgs {
     const unsigned* ready; unsigned epoch;
     // ... and the wait is BOUNDED: HIP promises no dispatch order, so a tree block of this launch may not be resident yet (or ever, while every
     // slot is held by a waiting trunk workgroup).  After spin_ticks of the 100-MHz wall clock — or at once when an earlier workgroup has already
-    // given up (*fuse_fault != 0) — the workgroup leaves its boards unevaluated, writes `epoch` to skipped[board] and counts itself in
-    // *fuse_fault; the games re-request (DevParams::eval_skipped) and the host falls back to separate launches (engine.hip poll_fuse_fault).
-    unsigned* skipped; int* fuse_fault; unsigned spin_ticks;
+    // given up (*fuse_fault != 0) — the workgroup leaves its boards unevaluated and counts itself in *fuse_fault; a workgroup that does take
+    // its boards on writes `epoch` to eval_done[board], so the games of the others re-request (DevParams::eval_done) and the host falls back to
+    // separate launches (engine.hip poll_fuse_fault).
+    unsigned* eval_done; int* fuse_fault; unsigned spin_ticks;
     unsigned test_fault_mod;                        // test hook (gaz_engine_debug_fused_fault): workgroups with index % mod == 1 behave as if their wait had timed out
     // B0 (Gomoku, round 2): the FIRST block of the network — 256 stem channels -> 128 with a 1x1 projection on the skip path
     // (Net/ResNet/ResNet_Block.py:21-33) — runs inside this launch too, ahead of blocks 1..: x0 = raw stem output [M][256];
@@ -50,6 +51,11 @@ struct TrunkArgs {
     // nothing but zero padding on the three taps that look across its edge, and the kernel variants built with SKIPSET != 0 leave its MFMAs
     // out there (conv_taps_static; the host launches them only with permutations that deliver exactly the masks they assume).
     const uint8_t* perm; const uint8_t* perm_small;     // tile_rows-shaped tiles; small_rows-shaped tiles (k_trunk_mix)
+    // ... and where the tile's boards sit in the LDS images: byte b = image row of cell 0 of board b (tile_perm.hpp TileLayout::boff; natural =
+    // b * H * W).  Shifting a board by a row or two changes nothing for the convolution (a board's cells stay contiguous, neighbours are
+    // row +- 1, +- W) but lets every permuted MFMA tile hold exactly two rows of each residue mod 8, the swizzle's conflict-free condition for the
+    // fragment reads of EVERY tap (round 3: SQ_LDS_BANK_CONFLICT back from 35.6 M to the natural order's level).  Used by the SKIPSET variants only.
+    unsigned boff, boff_small;
     // HEADS: the first convolution of both heads (k_conv_heads' operands) from the final image instead of writing xout
     const bf16_t* hw; const float* hbias;                                         // [9][8 k-steps][2][32][8]; [32]
     const float* p_fs; const float* p_ft; const float* v_fs; const float* v_ft; float* p_feat; float* v_feat;   // [HW * 8] flat BN; [B][HW * 8]
@@ -95,8 +101,9 @@ template <bool M16> __device__ __forceinline__ int swz_inv(int sp, int row) { re
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
 // NW = waves per workgroup (4; 8 for the 256-row Gomoku tile: WM = 4 waves down the cells, one workgroup per CU with both images in LDS).
 template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
-__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows, const uint8_t* perm = nullptr) {
+__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows, const uint8_t* perm = nullptr, const unsigned boffp = 0) {
     static_assert(!B0 || (M16 && !STEM && !HEADS && !RESG), "block 0 inside the launch: 16x16x32 build with both images in LDS");
+    static_assert(SKIPSET == 0 || (STEM && HEADS && M16), "board offsets in the image: only where the kernel itself maps image rows to global rows");
     constexpr int SL0 = B0 ? 29 : 0;                // weight slices of block 0 ahead of the regular blocks' 18 each
     constexpr int BN = 128, SLOTS = 16, WM = NW / WN, TN = 4 / WN, KS = 8, ROWS = 32 * TM * WM, ZROW = ROWS, BSL = BN * SLOTS, THREADS = 64 * NW;
     static_assert(NW == 4 || (!STEM && !HEADS), "stem / heads phases assume four waves");
@@ -117,6 +124,22 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lhi = lane >> 5;
     const int HW = a.H * a.W;
+    // image row -> (cell of its board, global row); false for padding rows and rows beyond the batch.  Natural layout: image row q <-> global row
+    // m0 + q; SKIPSET variants: board b of the tile starts at image row byte b of boffp (TrunkArgs::boff)
+    auto locate = [&](const int row, int& cell, long& grow) -> bool {
+        if constexpr (SKIPSET == 0) {
+            cell = row % HW; grow = m0 + row;
+            return row < tile_rows && grow < a.M;
+        } else {
+            bool ok = false; cell = 0; grow = 0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int o = (int)((boffp >> (8 * b)) & 0xFFu);
+                if (b * HW < tile_rows && row >= o && row < o + HW) { ok = true; cell = row - o; grow = m0 + b * HW + cell; }
+            }
+            return ok && grow < a.M;
+        }
+    };
     const uint4* in4 = reinterpret_cast<const uint4*>(a.xin);
     const int last_slice = SL0 + a.nblocks * 18 - 1;
     TR_STAMP(0);
@@ -171,8 +194,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     for (int tm = 0; tm < TM; ++tm) {
         lrow[tm] = (wm * TM + tm) * 32 + l31;
         unsigned mm = 0;
-        if (lrow[tm] < tile_rows && m0 + lrow[tm] < a.M) {
-            const int cell = lrow[tm] % HW, y = cell / a.W, x = cell % a.W;
+        int cell; long grow_;
+        if (locate(lrow[tm], cell, grow_)) {
+            const int y = cell / a.W, x = cell % a.W;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -207,11 +231,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         asm volatile("" ::: "memory");              // no plane load may be hoisted above the poll
     }
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
-    if (STEM && a.ready && __builtin_amdgcn_readfirstlane(gave_up)) {   // (scalar branch) leave the tile out: every board of it is marked, the tree re-requests (DevParams::eval_skipped)
-        const long b = m0 / HW + tid;
-        if (tid < tile_rows / HW && b * HW < a.M && a.skipped) __hip_atomic_store(a.skipped + b, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
-        return;
+    if (STEM && a.ready) {
+        if (__builtin_amdgcn_readfirstlane(gave_up)) {   // (scalar branch) leave the tile out: no board of it is marked, their games re-request (DevParams::eval_done)
+            if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
+            return;
+        }
+        const long b = m0 / HW + tid;                   // this launch evaluates these boards (read by the NEXT launch's tree step)
+        if (tid < tile_rows / HW && b * HW < a.M && a.eval_done) a.eval_done[b] = a.epoch;
     }
     TR_STAMP(1);
 
@@ -228,8 +254,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             for (int tn = 0; tn < TN; ++tn) sw[ks2][tn] = a.stem_frag[(ks2 * 2 + lhi) * 128 + col0 + tn * 32];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const long gr = m0 + lrow[tm];
-            const bool rok = lrow[tm] < tile_rows && gr < a.M;
+            int cell_; long gr;
+            const bool rok = locate(lrow[tm], cell_, gr);
             uint4 cf[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
@@ -325,8 +351,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         const int mrow = wm * TM * 32 + t * 16 + l15;
         crow[t] = perm ? (int)perm[mrow] : mrow;
         unsigned mm = 0;
-        if (crow[t] < tile_rows && m0 + crow[t] < a.M) {
-            const int cell = crow[t] % HW, y = cell / a.W, x = cell % a.W;
+        int cell; long grow_;
+        if (locate(crow[t], cell, grow_)) {
+            const int y = cell / a.W, x = cell % a.W;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 const int dy = q / 3 - 1, dx = q % 3 - 1;
@@ -760,8 +787,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         for (int g = 0; g < HRING; ++g) hfr[g] = ldh(g / KS, g % KS);
         const int hrow = waveh * 32 + l31h;         // cell tile `wave` of the workgroup
         unsigned hmask = 0;
-        if (hrow < tile_rows && m0 + hrow < a.M) {
-            const int cell = hrow % HW, y = cell / a.W, x = cell % a.W;
+        int hcell; long hgr;
+        const bool hok = locate(hrow, hcell, hgr);
+        if (hok) {
+            const int cell = hcell, y = cell / a.W, x = cell % a.W;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -793,9 +822,9 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             }
         }
         // lane: cell hrow, channels 8 j + 4 lhi + q: j = 0 policy head, j = 1 value head, j = 2, 3 padding
-        const long gr = m0 + hrow;
-        if (hrow < tile_rows && gr < a.M) {
-            const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = (int)((unsigned)gr - b * (unsigned)HW);
+        const long gr = hgr;
+        if (hok) {
+            const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = hcell;
             const int f = cell * 8 + 4 * lhih;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -823,7 +852,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 
 template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0, SKIPSET>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIPSET ? a.perm : nullptr);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0, SKIPSET>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIPSET ? a.perm : nullptr, a.boff);
 }
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
@@ -833,8 +862,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
 // rounds, the last one cheaper.
 template <int RING, int OCC, bool STEM, bool HEADS, bool M16 = false, bool SKIP = false>
 __global__ __launch_bounds__(TR_THREADS, OCC) void k_trunk_mix(TrunkArgs a) {
-    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 1 : 0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr);
-    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr);
+    if ((int)blockIdx.x < a.n_big) trunk_tile<2, 2, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 1 : 0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIP ? a.perm : nullptr, a.boff);
+    else trunk_tile<3, 4, RING, STEM, HEADS, false, M16, 4, false, SKIP ? 2 : 0>(a, (long)a.n_big * a.tile_rows + (long)((int)blockIdx.x - a.n_big) * a.small_rows, a.small_rows, SKIP ? a.perm_small : nullptr, a.boff_small);
 }
 
 }  // namespace gaz

@@ -247,7 +247,7 @@ def test_emu_repack_keeps_every_game_gumbel_and_compaction(emu_lib, oracle):
 
 @pytest.mark.parametrize("search,cache", [("puct", 0), ("gumbel", 0), ("puct", 12)])
 def test_emu_skipped_evaluations_are_requested_again(emu_lib, oracle, search, cache):
-    """The recovery path of the fused launch's BOUNDED hand-over (trunk.hpp TrunkArgs::spin_ticks, DevParams::eval_skipped): a trunk workgroup
+    """The recovery path of the fused launch's BOUNDED hand-over (trunk.hpp TrunkArgs::spin_ticks, DevParams::eval_done): a trunk workgroup
     that gives up leaves its boards unevaluated and marks them.  gaz_engine_debug_fused_fault injects exactly that on this build (marks the
     games, poisons their outputs with NaN, raises the fault counter): the marked games must keep their requests pending and be evaluated by the
     next wave — finished games identical to the oracle's — and the host must count the faults at its next synchronisation point."""

@@ -43,9 +43,16 @@ def read_b64_conflicts(addr_of_lane):
     return sum(group_cycles([addr_of_lane[l] for l in range(32 * q, 32 * q + 32)], 8, 64) - 1 for q in range(2))
 
 
-def tile_conflicts(perm, H, W, boards, rows, wave_rows, n_ct, skip):
-    """conflict cycles of ONE convolution pair (conv1 + h write + conv2 + epilogue) of one workgroup; perm None = natural order"""
+def tile_conflicts(perm, H, W, boff, rows, wave_rows, n_ct, skip):
+    """conflict cycles of ONE convolution pair (conv1 + h write + conv2 + epilogue) of one workgroup; perm None = natural order;
+    boff = image row of each board's cell 0 (tile_perm.hpp TileLayout::boff)"""
     HW = H * W
+
+    def cell_of(r):
+        for o in boff:
+            if o <= r < o + HW:
+                return r - o
+        return None
     ZROW = rows
     n_wr = rows // wave_rows
     NC = wave_rows // 16
@@ -65,8 +72,8 @@ def tile_conflicts(perm, H, W, boards, rows, wave_rows, n_ct, skip):
                     l15, lq = lane & 15, lane >> 4
                     r = crow[t][l15]
                     ok = False
-                    if r < boards * HW:
-                        y, x = divmod(r % HW, W)
+                    if cell_of(r) is not None:
+                        y, x = divmod(cell_of(r), W)
                         ok = 0 <= y + dy < H and 0 <= x + dx < W
                     ar = r + off if ok else ZROW + ((r + off) & 15)
                     addr[lane] = ar * 256 + (swz(lq, ar) << 4)
@@ -95,18 +102,21 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, "tests", "emu", "libgaz_emu.so"))
 
     def perm_of(H, W, boards, rows, wave_rows, per):
-        p = np.zeros(rows, np.uint8); m = np.zeros(rows // 16, np.uint32)
-        n = lib.gaz_test_tile_perm(H, W, boards, rows, wave_rows, per, p.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+        p = np.zeros(rows, np.uint8); m = np.zeros(rows // 16, np.uint32); bo = np.zeros(boards, np.int32); cl = C.c_int(0)
+        n = lib.gaz_test_tile_perm(H, W, boards, rows, wave_rows, per, p.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                   bo.ctypes.data_as(C.c_void_p), C.byref(cl))
         assert n == rows
-        return p.tolist(), m.tolist()
+        return p.tolist(), bo.tolist(), cl.value
 
     convs = 6                                             # blocks: two convolutions each
-    for label, use_perm in (("natural order", False), ("tile_perm", True)):
+    for label, use_perm in (("natural order", False), ("tile_layout", True)):
         total = 0
         for (boards, rows, wave_rows, per, n_ct, nwg, skip) in ((3, 128, 64, 2, 4, 1024, SKIP_BIG), (2, 96, 96, 3, 2, 512, SKIP_SMALL)):
-            p, m = perm_of(6, 7, boards, rows, wave_rows, per)
-            r, w, nr, nw = tile_conflicts(p if use_perm else None, 6, 7, boards, rows, wave_rows, n_ct, skip if use_perm else None)
-            print(f"{label:14s} {rows:3d}-row tile: fragment-read conflict cycles / block {r:6d} ({nr} reads), b64 epilogue conflicts {w:6d}; x {nwg} workgroups x {convs} blocks")
+            p, bo, cl = perm_of(6, 7, boards, rows, wave_rows, per)
+            if not use_perm:
+                bo = [b * 42 for b in range(boards)]
+            r, w, nr, nw = tile_conflicts(p if use_perm else None, 6, 7, bo, rows, wave_rows, n_ct, skip if use_perm else None)
+            print(f"{label:14s} {rows:3d}-row tile, boards at image rows {bo}: fragment-read conflict cycles / block {r:6d} ({nr} reads), b64 epilogue conflicts {w:6d}; x {nwg} workgroups x {convs} blocks")
             total += (r + w) * nwg * convs
         print(f"{label:14s} predicted SQ_LDS_BANK_CONFLICT per launch (block loop only): {total / 1e6:.1f} M")
 
