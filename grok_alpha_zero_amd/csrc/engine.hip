@@ -513,8 +513,11 @@ template <class G> struct EngineT : gaz_engine {
         // with the evaluation cache too (measured 67.5 k vs 64.3 k positions/s): a team's probe reads its OWN row, and the table is
         // written by k_cache_insert between launches as before.  GAZ_FUSE_CACHE=0 -> separate launches when the cache is on
         static const bool with_cache = !(getenv("GAZ_FUSE_CACHE") && atoi(getenv("GAZ_FUSE_CACHE")) == 0);
-        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || cfg.search != GAZ_SEARCH_PUCT || (E.cache && !with_cache) || E.compact || !eval || !eval->supports_split()) return false;
-        if (getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
+        const bool gumbel = cfg.search == GAZ_SEARCH_GUMBEL;
+        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || (E.cache && !with_cache) || E.compact || !eval || !eval->supports_split()) return false;
+        // round 3: the Gumbel search too (BASELINE configs[4]; its tree step is 17 % of a wave when launched separately).  GAZ_FUSE_GUMBEL=0 -> separate
+        if (gumbel && ((getenv("GAZ_FUSE_GUMBEL") && atoi(getenv("GAZ_FUSE_GUMBEL")) == 0) || E.cache)) return false;
+        if (!gumbel && getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
         if (dalloc(&d_done, (size_t)E.n_games) || !ensure_skip_buffers()) return false;
         fuse_state = 1;
         return true;
@@ -589,7 +592,11 @@ template <class G> struct EngineT : gaz_engine {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
                 if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
                 DevParams<G> Ef = wave_params(); Ef.done_flag = d_done;
-                launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
+                const bool launched = cfg.search == GAZ_SEARCH_GUMBEL ? launch_wave_trunk_c4_gumbel(stream, &Ef, 0, n_eff, plan) : launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
+                if (!launched) {                     // no fused kernel for this trunk variant: separate launches, for good
+                    fuse_state = 0; --fuse_epoch;
+                    return one_wave(with_eval);
+                }
                 prev_marked = true;                  // the trunk workgroups of this launch mark the boards they evaluate
                 if (timing) hipEventRecord(e1, stream);
                 eval->forward_heads(stream, E.nn_policy, E.nn_value, n_eff, 0);
@@ -966,7 +973,7 @@ template <class G> struct EngineT : gaz_engine {
         double f = 0; const char* k = eval ? eval->dominant_kernel(n_launch, &f) : "";
         if (eval && can_pipeline()) { double fa = 0; eval->dominant_kernel(E.n_games, &fa); f = fa / n_grp; }
         std::string label = k;
-        if (fuse_state == 1 && fuse_enabled) label = "k_wave_trunk = " + label + " FUSED with the PUCT tree step of the same wave (one launch: tree blocks first, trunk workgroups start on the "
+        if (fuse_state == 1 && fuse_enabled) label = "k_wave_trunk = " + label + " FUSED with the " + std::string(cfg.search == GAZ_SEARCH_GUMBEL ? "Gumbel" : "PUCT") + " tree step of the same wave (one launch: tree blocks first, trunk workgroups start on the "
                                      "boards whose games are done; the launch duration therefore includes the part of the tree step it could not hide)";
         if (name && cap > 0) { strncpy(name, label.c_str(), cap - 1); name[cap - 1] = 0; }
         if (flops) *flops = f;

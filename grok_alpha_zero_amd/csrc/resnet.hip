@@ -1234,6 +1234,27 @@ template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void 
     wave_trunk_body<MIX, SKIP, GP4, PuctLocal<GP4>, false>(E, g0, g1, n_tree_blocks, a);
 }
 
+// The Gumbel search (MCTS_Gumbel.py:562-679) in the same launch shape.  TEAMS: four games per wavefront (16 games per tree block, as the PUCT
+// launch) or one game per wavefront (4 per tree block: less lock-step, but four times the tree blocks ahead of the trunk workgroups).
+template <bool MIX, bool SKIP, bool TEAMS> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk_gumbel(DevParams<Game<GAME_C4>> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+    if constexpr (TEAMS) wave_trunk_body<MIX, SKIP, GP4, GumbelLocal<GP4>, true>(*reinterpret_cast<const DevParams<GP4>*>(&E), g0, g1, n_tree_blocks, a);
+    else wave_trunk_body<MIX, SKIP, Game<GAME_C4>, GumbelLocal<Game<GAME_C4>>, true>(E, g0, g1, n_tree_blocks, a);
+}
+
+bool launch_wave_trunk_c4_gumbel(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {
+    if (!plan || !dev_params) return false;
+    const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
+    const DevParams<Game<GAME_C4>>& E = *static_cast<const DevParams<Game<GAME_C4>>*>(dev_params);
+    static const bool teams = !(getenv("GAZ_FUSE_GUMBEL_TEAMS") && atoi(getenv("GAZ_FUSE_GUMBEL_TEAMS")) == 0);
+    const int per_block = (TR_THREADS / WAVE) * (teams ? WAVE / GP4::TEAM : 1);
+    const int n_tree = (g1 - g0 + per_block - 1) / per_block;
+    const bool skip = P.args.perm && P.args.perm_small;
+    if (!P.mix || !skip) return false;              // only the headline trunk variant is built for this launch
+    if (teams) hipLaunchKernelGGL((k_wave_trunk_gumbel<true, true, true>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    else hipLaunchKernelGGL((k_wave_trunk_gumbel<true, true, false>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    return true;
+}
+
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {
     if (!plan || !dev_params) return false;
     const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
