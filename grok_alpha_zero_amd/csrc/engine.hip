@@ -489,6 +489,7 @@ template <class G> struct EngineT : gaz_engine {
     // does not mark its boards in d_evaldone; their games keep their requests pending (no result changes), and poll_fuse_fault() — at every host
     // synchronisation point — switches this engine to separate launches for good.
     uint32_t* d_done = nullptr; uint32_t* d_evaldone = nullptr; int32_t* d_fault = nullptr;
+    unsigned long long* d_queue = nullptr;           // completion queue of the fused launch (DevParams::done_queue); GAZ_FUSE_QUEUE=0 -> a flag per board
     uint32_t fuse_epoch = 0; int fuse_state = -1;     // -1 not decided, 0 off, 1 on
     uint64_t fuse_faults = 0;                        // trunk workgroups that gave up waiting, over the engine's life (get_stats [13])
     unsigned debug_fault_mod = 0;                    // test hook: gaz_engine_debug_fused_fault
@@ -519,6 +520,7 @@ template <class G> struct EngineT : gaz_engine {
         if (gumbel && ((getenv("GAZ_FUSE_GUMBEL") && atoi(getenv("GAZ_FUSE_GUMBEL")) == 0) || E.cache)) return false;
         if (!gumbel && getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
         if (dalloc(&d_done, (size_t)E.n_games) || !ensure_skip_buffers()) return false;
+        if (!(getenv("GAZ_FUSE_QUEUE") && atoi(getenv("GAZ_FUSE_QUEUE")) == 0) && dalloc(&d_queue, (size_t)E.n_games + 64)) return false;
         fuse_state = 1;
         return true;
     }
@@ -586,18 +588,37 @@ template <class G> struct EngineT : gaz_engine {
     int one_wave(bool with_eval) {
         if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
-            const FuseHandoff ho{d_done, fuse_epoch + 1, d_evaldone, d_fault, SPIN_TICKS, debug_fault_mod};
+            // diagnostic: GAZ_FUSED_STAMPS=<file>[:n] -> wall-clock stamps of every block of the n-th fused launch (tools/fused_timeline.py)
+            static const char* stamp_spec = getenv("GAZ_FUSED_STAMPS");
+            static const long stamp_at = stamp_spec && strchr(stamp_spec, ':') ? atol(strchr(stamp_spec, ':') + 1) : 3000;
+            unsigned long long* d_stamps = nullptr;
+            const size_t stamp_blocks = (size_t)n_eff + 4096;              // >= tree blocks + trunk workgroups
+            if (stamp_spec && n_waves_total == stamp_at && hipMalloc((void**)&d_stamps, stamp_blocks * 128 * 8) == hipSuccess) hipMemsetAsync(d_stamps, 0, stamp_blocks * 128 * 8, stream);
+            const FuseHandoff ho{d_done, fuse_epoch + 1, d_evaldone, d_fault, SPIN_TICKS, debug_fault_mod, d_stamps, d_queue};
             const void* plan = eval->trunk_plan(E.nn_in, n_eff, 0, ho);
             if (plan) {
                 hipEvent_t e0 = 0, e1 = 0, e2 = 0;
                 if (timing) { e0 = new_event(); e1 = new_event(); e2 = new_event(); hipEventRecord(e0, stream); }
                 DevParams<G> Ef = wave_params(); Ef.done_flag = d_done;
+                if (eval->plan_uses_queue(plan)) {   // the trunk workgroups take queue entries: the tree blocks rank their games as they finish
+                    typedef typename PuctVariant<G>::type GPq;
+                    static const bool gumbel_teams = !(getenv("GAZ_FUSE_GUMBEL_TEAMS") && atoi(getenv("GAZ_FUSE_GUMBEL_TEAMS")) == 0);
+                    const int gpb = 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
+                    Ef.done_queue = d_queue; Ef.queue_gpb = gpb; Ef.queue_nfull = n_eff / gpb; Ef.queue_rem = n_eff % gpb;
+                }
                 const bool launched = cfg.search == GAZ_SEARCH_GUMBEL ? launch_wave_trunk_c4_gumbel(stream, &Ef, 0, n_eff, plan) : launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
                 if (!launched) {                     // no fused kernel for this trunk variant: separate launches, for good
                     fuse_state = 0; --fuse_epoch;
                     return one_wave(with_eval);
                 }
                 prev_marked = true;                  // the trunk workgroups of this launch mark the boards they evaluate
+                if (d_stamps) {
+                    std::vector<unsigned long long> hst(stamp_blocks * 128);
+                    hipStreamSynchronize(stream);
+                    hipMemcpy(hst.data(), d_stamps, hst.size() * 8, hipMemcpyDeviceToHost); hipFree(d_stamps);
+                    std::string path(stamp_spec); if (path.find(':') != std::string::npos) path = path.substr(0, path.find(':'));
+                    if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(hst.data(), 8, hst.size(), f); fclose(f); }
+                }
                 if (timing) hipEventRecord(e1, stream);
                 eval->forward_heads(stream, E.nn_policy, E.nn_value, n_eff, 0);
                 if (E.cache) { Ef.eval_done = d_evaldone; GAZ_LAUNCH(k_cache_insert<G>, n_eff, WAVE, stream, Ef, 0, n_eff); E.cache_epoch++; }

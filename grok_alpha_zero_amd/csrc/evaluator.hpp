@@ -13,7 +13,9 @@
 namespace gaz {
 
 // what a fused tree + trunk launch hands from the tree teams to the trunk workgroups (trunk.hpp TrunkArgs::ready ... test_fault_mod)
-struct FuseHandoff { const unsigned* ready; unsigned epoch; unsigned* eval_done; int* fuse_fault; unsigned spin_ticks; unsigned test_fault_mod; };
+struct FuseHandoff { const unsigned* ready; unsigned epoch; unsigned* eval_done; int* fuse_fault; unsigned spin_ticks; unsigned test_fault_mod;
+                     unsigned long long* stamps;         // stamps: diagnostic (GAZ_FUSED_STAMPS), [block][128] or null
+                     const unsigned long long* queue; }; // completion queue (DevParams::done_queue) or null: ready[] flags per board
 
 struct Evaluator {
     virtual ~Evaluator() {}
@@ -31,6 +33,7 @@ struct Evaluator {
     // fused tree + trunk launch (resnet.hip k_wave_trunk): the trunk part as a launch PLAN (kernel arguments + grid) instead of a launch; the
     // planes of board b are valid once ready[b] == epoch (FuseHandoff, below).  Null = this evaluator / configuration cannot be fused.
     virtual const void* trunk_plan(const int8_t* in, int n, int p0, const struct FuseHandoff& h) { (void)in; (void)n; (void)p0; (void)h; return nullptr; }
+    virtual bool plan_uses_queue(const void* plan) const { (void)plan; return false; }      // did trunk_plan take FuseHandoff::queue on?
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }

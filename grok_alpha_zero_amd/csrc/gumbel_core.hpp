@@ -668,18 +668,18 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
 // one a dependent global-memory access.  The launch works on an LDS copy instead: one coalesced load on entry, one store on exit.
 template <class G> struct GumbelLocal { GameState<G> gs; GumbelState<G> gu; TreeState ts; };
 
-template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S, GumbelLocal<G>& L) {
+template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratch<G>& S, GumbelLocal<G>& L, uint32_t* block_rank = nullptr, int block = 0) {
     GameState<G>* gsG = &E.games[g];
     GumbelState<G>* guG = &reinterpret_cast<GumbelState<G>*>(E.gstate)[g];
     TreeState* tsG = &E.trees[(size_t)g * 2];
-    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g); return; }      // see puct_core.hpp game_step
+    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g, block_rank, block); return; }      // see puct_core.hpp game_step
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.gu, guG); copy_state_words<G>(&L.ts, tsG);
     wave_sync();
     g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
     wave_sync();
     copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(guG, &L.gu); copy_state_words<G>(tsG, &L.ts);
-    publish_done<G>(E, g);
+    publish_done<G>(E, g, block_rank, block);
     GAZ_PROF(6, tw0);
 }
 

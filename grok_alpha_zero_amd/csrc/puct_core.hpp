@@ -81,6 +81,13 @@ template <class G> struct DevParams {
     // never computed.  A game only loses a wave: its results cannot change.  (Marking success, not failure: a workgroup of THIS launch may give
     // up before this game's team has even started, and must not be able to disturb what the team reads about the previous launch.)
     uint32_t* eval_done;       // [n_games] or null
+    // completion queue of the fused launch (round 3; trunk.hpp TrunkArgs::queue): instead of a flag per game, a finished game's team appends the
+    // game to a queue and the trunk workgroups take ENTRIES, not fixed boards — the first tiles get whichever games finished first, and no
+    // workgroup sits on a slot waiting for one slow game (rows of an evaluator batch are independent bit for bit, so which tile evaluates a
+    // game cannot change its outputs).  No global atomics: a tree block ranks its own games by a counter in LDS, and entry (rank r, block j)
+    // sits at r * n_full + min(r, rem) + j — rank-major, so the entries of every block's fastest game come first.  Entry = epoch << 32 | game.
+    unsigned long long* done_queue;    // [n_games] or null (then done_flag is used)
+    int32_t queue_gpb, queue_nfull, queue_rem;   // games per tree block; blocks with that many games; games of the last, partial block
 };
 
 // stores / loads that meet at the device's point of coherence (no L1 / per-XCD L2 copy): used for the leaf rows and the done flags
@@ -1064,8 +1071,17 @@ template <class G, class T> GAZ_DEV void copy_state_words(T* dst, const T* src) 
 }
 
 // fused launch: the team's leaf row (coherent stores, encode_input) has reached memory -> publish the epoch
-template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g) {
+template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g, uint32_t* block_rank = nullptr, int block = 0) {
 #ifndef GAZ_HOST_EMU
+    if (E.done_queue && block_rank) {               // completion queue: this game is the rank-th of its tree block to finish
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tlane<G>() == 0) {
+            const int rank = (int)atomic_add(block_rank, 1u);              // LDS
+            const int entry = rank * E.queue_nfull + (rank < E.queue_rem ? rank : E.queue_rem) + block;
+            __hip_atomic_store(E.done_queue + entry, ((unsigned long long)E.wave_epoch << 32) | (unsigned)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (!E.done_flag) return;
     // every store of this wave — the leaf row included — has been acknowledged before the flag is written.  Inline asm with a memory clobber: the
     // compiler may neither sink a row store below it nor hoist the flag store above it (MI355X_MICROARCH.md, Valid forms: write-through payload ->
@@ -1081,18 +1097,18 @@ template <class G> GAZ_DEV bool eval_was_skipped(const DevParams<G>& E, int g) {
     return tuni<G>(E.eval_done[g]) != E.wave_epoch - 1;
 }
 
-template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L) {
+template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<G>& S, PuctLocal<G>& L, uint32_t* block_rank = nullptr, int block = 0) {
     GameState<G>* gsG = &E.games[g];
     TreeState* tsG = E.trees + (size_t)g * 2;
-    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g); return; }      // the request stays pending: same leaf row, evaluated by this wave
-    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); publish_done<G>(E, g); return; }
+    if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g, block_rank, block); return; }      // the request stays pending: same leaf row, evaluated by this wave
+    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); publish_done<G>(E, g, block_rank, block); return; }
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.ts[0], &tsG[0]); copy_state_words<G>(&L.ts[1], &tsG[1]);
     wave_sync();
     game_step_body<G>(E, g, S, L.gs, L.ts);
     wave_sync();
     copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(&tsG[0], &L.ts[0]); copy_state_words<G>(&tsG[1], &L.ts[1]);
-    publish_done<G>(E, g);
+    publish_done<G>(E, g, block_rank, block);
     GAZ_PROF(6, tw0);
 }
 

@@ -611,9 +611,11 @@ struct ResNetEvaluator : Evaluator {
     const void* trunk_plan(const int8_t* in, int n, int p0, const FuseHandoff& h) override {
         if (!trunk_m16 || !make_trunk_plan(in, n, p0, fused_plan)) return nullptr;
         TrunkArgs& r = fused_plan.args;
-        r.ready = h.ready; r.epoch = h.epoch; r.eval_done = h.eval_done; r.fuse_fault = h.fuse_fault; r.spin_ticks = h.spin_ticks; r.test_fault_mod = h.test_fault_mod;
+        r.ready = h.ready; r.epoch = h.epoch; r.eval_done = h.eval_done; r.fuse_fault = h.fuse_fault; r.spin_ticks = h.spin_ticks; r.test_fault_mod = h.test_fault_mod; r.stamps = h.stamps;
+        r.queue = (perm_big && perm_small && fused_plan.mix) ? h.queue : nullptr;       // the completion queue needs the variant that maps image rows to games itself
         return &fused_plan;
     }
+    bool plan_uses_queue(const void* plan) const override { return plan && static_cast<const TrunkLaunchPlan*>(plan)->args.queue != nullptr; }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         forward_trunk(s, in, n, timing, p0);
@@ -1199,19 +1201,29 @@ namespace gaz {
 
 typedef TeamGame<GAME_C4> GP4;
 
-// The tree role is a FUNCTION CALL, not inlined code: inlined, its scalar-register pressure (337 spilled SGPRs, parked in lanes of 6 VGPRs that
-// are then reserved for the whole kernel) pushed the trunk role of the edge-tile variant from 252 to 256 VGPRs + 7 spilled ones (32 B of scratch
-// per lane, read and written inside its block loop).  One call per tree block; the callee allocates its own registers.
-template <class GP, class LOCAL, bool GUMBEL> __device__ __attribute__((noinline)) void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
+// The tree role inlined or as a function call (-DGAZ_TREE_ROLE_ATTR='__attribute__((noinline))').  Inlined, its scalar-register pressure (337
+// spilled SGPRs, parked in lanes of 6 VGPRs that are then reserved for the whole kernel) costs the trunk role of the edge-tile variant a few
+// spilled VGPRs (256 + 7, none inside the tap loop: +1.4 % on a workgroup's compute time); as a call the trunk role is spill-free but the TREE
+// role — the launch's critical path — slows down by a quarter (callee-saved registers and spills go through scratch memory: tree waves 53 -> 66
+// us at the median, fused launch 509 -> 541 us, same box, tools/ab_fused.sh, gpurun_out r03 ab1).  Measured, inlined wins by 4 %: the default.
+#ifndef GAZ_TREE_ROLE_ATTR
+#define GAZ_TREE_ROLE_ATTR __forceinline__
+#endif
+template <class GP, class LOCAL, bool GUMBEL> __device__ GAZ_TREE_ROLE_ATTR void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
     constexpr int PER = WAVE / GP::TEAM, NT = (TR_THREADS / WAVE) * PER;
     Scratch<GP>* S = reinterpret_cast<Scratch<GP>*>(lds);
     LOCAL* L = reinterpret_cast<LOCAL*>(S + NT);
-    static_assert(NT * (sizeof(Scratch<GP>) + sizeof(LOCAL)) <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
+    uint32_t* rank = reinterpret_cast<uint32_t*>(L + NT);           // completion queue: how many games of this block have finished (DevParams::done_queue)
+    static_assert(NT * (sizeof(Scratch<GP>) + sizeof(LOCAL)) + 16 <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
+    if (E.done_queue) {
+        if (threadIdx.x == 0) *rank = 0;
+        __syncthreads();
+    }
     const int w = threadIdx.x >> 6, t = team_in_wave<GP>(), i = w * PER + t;
     const int g = g0 + ((int)blockIdx.x * (TR_THREADS / WAVE) + w) * PER + t;
     if (g < g1) {
-        if constexpr (GUMBEL) g_game_step<GP>(E, g, S[i], L[i]);
-        else game_step<GP>(E, g, S[i], L[i]);
+        if constexpr (GUMBEL) g_game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
+        else game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
     }
 }
 
@@ -1221,7 +1233,9 @@ __device__ __forceinline__ void wave_trunk_body(const DevParams<GP>& E, int g0, 
         // ---- tree role: wave w of the block steps games [(4 b + w) PER, +PER); its scratch lives in the launch's dynamic LDS
         extern __shared__ uint4 lds[];
         const DevParams<GP> El = E;                 // the callee takes an address: copy the kernel argument to the stack HERE, not at kernel entry for every workgroup
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(size_t)blockIdx.x * 128 + (threadIdx.x >> 6)] = wall_clock64();            // GAZ_FUSED_STAMPS: wave w starts at [w] ...
         tree_role<GP, LOCAL, GUMBEL>(El, g0, g1, lds);
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(size_t)blockIdx.x * 128 + 4 + (threadIdx.x >> 6)] = wall_clock64();        // ... and ends at [4 + w]
         return;
     }
     // ---- trunk role: exactly k_trunk_mix / k_trunk of trunk.hpp on workgroup index bid

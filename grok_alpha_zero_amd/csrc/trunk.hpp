@@ -40,6 +40,11 @@ struct TrunkArgs {
     // its boards on writes `epoch` to eval_done[board], so the games of the others re-request (DevParams::eval_done) and the host falls back to
     // separate launches (engine.hip poll_fuse_fault).
     unsigned* eval_done; int* fuse_fault; unsigned spin_ticks;
+    // completion queue (round 3; puct_core.hpp DevParams::done_queue): with queue != null board b of the batch is not game b but ENTRY b of the
+    // launch's queue — whichever game finished b-th in rank-major order — so the first workgroups run on the games that are ready first.  The
+    // workgroup waits (bounded, as above) for its entries' tags to reach `epoch`, then reads its planes from and writes its head features to
+    // the rows of those games.  SKIPSET variants only (they map image rows to global rows themselves, see boff).
+    const unsigned long long* queue;
     unsigned test_fault_mod;                        // test hook (gaz_engine_debug_fused_fault): workgroups with index % mod == 1 behave as if their wait had timed out
     // B0 (Gomoku, round 2): the FIRST block of the network — 256 stem channels -> 128 with a 1x1 projection on the skip path
     // (Net/ResNet/ResNet_Block.py:21-33) — runs inside this launch too, ahead of blocks 1..: x0 = raw stem output [M][256];
@@ -79,7 +84,8 @@ __device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two
 #define TR_STAMP(i) do { if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 128 + (i)] = wall_clock64(); a.stamps[(size_t)blockIdx.x * 128 + 64 + (i)] = clock64(); } } while (0)
 constexpr int TR_THREADS = 256, TR_PRM = 5 * 128;
 constexpr int TR_ZROWS = 16;                        // zero rows behind the operand image, see trunk_tile
-constexpr size_t trunk_lds_bytes(int rows, bool resg = false) { return (size_t)((resg ? 1 : 2) * rows + TR_ZROWS) * 256 + 2 * TR_PRM * 4; }
+constexpr int TR_XTRA = 64;                          // bytes behind the parameter sets: the "gave up" word and the tile's game indices (completion queue)
+constexpr size_t trunk_lds_bytes(int rows, bool resg = false) { return (size_t)((resg ? 1 : 2) * rows + TR_ZROWS) * 256 + 2 * TR_PRM * 4 + TR_XTRA; }
 
 // Image swizzle: 16-byte slot of k-group g (channels 8 g ..+7) in image row `row`.
 //  * 32x32x16 build: g ^ (row & 15).  A ds_read_b128 is served in four groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
@@ -116,6 +122,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     // banks its own row would have used, so the group's access pattern stays the conflict-free one.
     uint4* Xs = lds + (ROWS + TR_ZROWS) * SLOTS;  // raw stream (not with RESG)
     float* Ps = reinterpret_cast<float*>(Xs + (RESG ? 0 : ROWS * SLOTS));      // [2][5][128]
+    volatile int* Xt = reinterpret_cast<volatile int*>(Ps + 2 * TR_PRM);       // [TR_XTRA / 4]: [0] gave up, [1..3] game index of the tile's boards (completion queue)
     static_assert(!RESG || (!STEM && !HEADS), "the stem / heads phases work on the x image");
     constexpr int NB = TM >= 4 ? 2 : 4, PD = NB - 1;   // operand-fragment buffers and prefetch distance in k-steps
     char* Ab = reinterpret_cast<char*>(As);
@@ -135,7 +142,12 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const int o = (int)((boffp >> (8 * b)) & 0xFFu);
-                if (b * HW < tile_rows && row >= o && row < o + HW) { ok = true; cell = row - o; grow = m0 + b * HW + cell; }
+                if (b * HW < tile_rows && row >= o && row < o + HW) {
+                    cell = row - o;
+                    // completion queue: board b of the tile is the game its queue entry names (Xt[1 + b], written before the barrier below; -1 = no entry)
+                    const long gb = a.queue ? (long)Xt[1 + b] : m0 / HW + b;
+                    ok = gb >= 0; grow = gb * HW + cell;
+                }
             }
             return ok && grow < a.M;
         }
@@ -188,11 +200,57 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) bfr[g][tn] = ldb(0, g, tn);
 
-    // per-lane geometry: cell lrow[tm] of the tile is this lane's column of the cell operand; 9 tap-validity bits
+    // per-lane geometry: cell lrow[tm] of the tile is this lane's column of the cell operand (its 9 tap-validity bits: behind the barrier below)
     int lrow[TM]; unsigned vmask[TM];
 #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) lrow[tm] = (wm * TM + tm) * 32 + l31;
+    // byte offset of this lane's 8-byte group j (channels 8 cslot + 4 lhi ..+3, cslot = (wn TN + tn) 4 + j) of cell lrow[tm] in either image
+    auto img_off = [&](int tm, int tn, int j) -> int {
+        const int row = lrow[tm], cslot = (wn * TN + tn) * 4 + j;
+        return row * 256 + (swz_slot<M16>(cslot, row) << 4) + lhi * 8;
+    };
+    // fused launch: "this workgroup's wait ran out" (Xt[0]), workgroup-uniform after the barrier
+    if (STEM && (a.ready || a.queue)) {             // wait for the tree teams of this tile's boards (see TrunkArgs::ready / queue), for a bounded time
+        if (tid == 0) Xt[0] = 0;                    // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
+        const long b = m0 / HW + tid;               // board of the batch = done flag index, or queue entry
+        if (tid < tile_rows / HW) {
+            int game = -1;
+            if (b * HW < a.M) {
+                bool fail = a.test_fault_mod && blockIdx.x % a.test_fault_mod == 1;
+                auto arrived = [&]() -> bool {
+                    if (SKIPSET != 0 && a.queue) {
+                        const unsigned long long v = __hip_atomic_load(a.queue + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        game = (int)(unsigned)v;
+                        return (unsigned)(v >> 32) == a.epoch;
+                    }
+                    game = (int)b;
+                    return (int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) >= 0;
+                };
+                if (!fail && !arrived()) {
+                    const unsigned long long t0 = wall_clock64();
+                    fail = a.fuse_fault && __hip_atomic_load(a.fuse_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                    while (!fail && !arrived()) {
+                        __builtin_amdgcn_s_sleep(16);
+                        fail = wall_clock64() - t0 > (unsigned long long)a.spin_ticks;
+                    }
+                }
+                if (fail) { Xt[0] = 1; game = -1; }
+            }
+            Xt[1 + tid] = game;
+        }
+        asm volatile("" ::: "memory");              // no plane load may be hoisted above the poll
+    }
+    __syncthreads();                                // Xs, block 0's parameters and the zero row landed
+    if (STEM && (a.ready || a.queue)) {
+        if (__builtin_amdgcn_readfirstlane(Xt[0])) {     // (scalar branch) leave the tile out: no board of it is marked, their games re-request (DevParams::eval_done)
+            if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
+            return;
+        }
+        if (tid < tile_rows / HW && Xt[1 + tid] >= 0 && a.eval_done) a.eval_done[Xt[1 + tid]] = a.epoch;      // this launch evaluates these games (read by the NEXT launch's tree step)
+    }
+    // (behind the barrier: with the completion queue, which games — hence which rows are valid — is only known now)
+#pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        lrow[tm] = (wm * TM + tm) * 32 + l31;
         unsigned mm = 0;
         int cell; long grow_;
         if (locate(lrow[tm], cell, grow_)) {
@@ -204,40 +262,6 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             }
         }
         vmask[tm] = mm;
-    }
-    // byte offset of this lane's 8-byte group j (channels 8 cslot + 4 lhi ..+3, cslot = (wn TN + tn) 4 + j) of cell lrow[tm] in either image
-    auto img_off = [&](int tm, int tn, int j) -> int {
-        const int row = lrow[tm], cslot = (wn * TN + tn) * 4 + j;
-        return row * 256 + (swz_slot<M16>(cslot, row) << 4) + lhi * 8;
-    };
-    // fused launch: "this workgroup's wait ran out", workgroup-uniform after the barrier.  A word of the idle parameter set (free until block 0
-    // stages the next block's vectors): a static __shared__ variable would move the dynamic segment off its 256-byte boundary (ldsb check below)
-    volatile int& gave_up = *reinterpret_cast<volatile int*>(Ps + TR_PRM + 256);
-    if (STEM && a.ready) {                          // wait for the tree teams of this tile's boards (see TrunkArgs::ready), for a bounded time
-        if (tid == 0) gave_up = 0;                  // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
-        const long b = m0 / HW + tid;
-        if (tid < tile_rows / HW && b * HW < a.M) {
-            bool fail = a.test_fault_mod && blockIdx.x % a.test_fault_mod == 1;
-            if (!fail && (int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
-                const unsigned long long t0 = wall_clock64();
-                fail = a.fuse_fault && __hip_atomic_load(a.fuse_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-                while (!fail && (int)(__hip_atomic_load(a.ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
-                    __builtin_amdgcn_s_sleep(16);
-                    fail = wall_clock64() - t0 > (unsigned long long)a.spin_ticks;
-                }
-            }
-            if (fail) gave_up = 1;
-        }
-        asm volatile("" ::: "memory");              // no plane load may be hoisted above the poll
-    }
-    __syncthreads();                                // Xs, block 0's parameters and the zero row landed
-    if (STEM && a.ready) {
-        if (__builtin_amdgcn_readfirstlane(gave_up)) {   // (scalar branch) leave the tile out: no board of it is marked, their games re-request (DevParams::eval_done)
-            if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
-            return;
-        }
-        const long b = m0 / HW + tid;                   // this launch evaluates these boards (read by the NEXT launch's tree step)
-        if (tid < tile_rows / HW && b * HW < a.M && a.eval_done) a.eval_done[b] = a.epoch;
     }
     TR_STAMP(1);
 
@@ -266,7 +290,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                     int packed = 0;
                     if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u))   // fused launch: the row was written during this launch -> read it where it was written to
-                        packed = a.ready ? __hip_atomic_load(in32 + (gr + dy * a.W + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : in32[gr + dy * a.W + dx];
+                        packed = (a.ready || a.queue) ? __hip_atomic_load(in32 + (gr + dy * a.W + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : in32[gr + dy * a.W + dx];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) pl[h * 4 + c] = (int)(int8_t)((packed >> (8 * c)) & 0xFF);
                 }
