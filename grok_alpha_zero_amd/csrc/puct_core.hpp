@@ -849,7 +849,12 @@ template <class G> GAZ_DEV bool ring_push(const DevParams<G>& E, int g, GameStat
 }
 
 // One launch of the wave kernel for game g: consume the pending evaluation, then run until the next one.
-template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, TreeState* trees) {
+// `fin` = what the caller does once this game's step is over (state back to HBM, done flag / queue entry of the fused launch).  It runs INSIDE the
+// phase loop, at the point where the game yields: with several games per wavefront the code behind a loop only executes once the LAST team has
+// left it (the compiler gives a divergent loop one exit), so a game that needed a single simulation used to publish its leaf row when the
+// slowest game of its wavefront was done — 53 us instead of 22 at the median (tools/fused_timeline.py).  The loop therefore runs until every
+// team of the wavefront has yielded, a team that has yielded sitting out the remaining iterations.
+template <class G, class Fin> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, TreeState* trees, Fin&& fin) {
     using RL = RecLayout<G>;
 
     const long long tp0 = GAZ_PROF_NOW();
@@ -868,7 +873,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
 
     GAZ_PROF(0, tp0);
     int tree_only = 0;   // simulations completed in this launch without an evaluation
-    for (int guard = 0; guard < 100000; ++guard) {
+    auto phase_step = [&]() -> bool {               // one phase of the state machine; true = the game yields for this launch
         const int phase = tuni<G>(gs.phase);
         if (phase == PH_NEW_GAME) {                                    // Game.__init__ + Self_Play.__init__ (Self_Play.py:37-57)
             for (int c = tlane<G>(); c < G::BPAD; c += G::TEAM) gs.board[c] = 0;
@@ -881,7 +886,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             wave_sync();
         } else if (phase == PH_ROOT) {
             const int todo = tuni<G>(gs.roots_todo);
-            if (todo == 0) { if (tlane<G>() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
+            if (todo == 0) { if (tlane<G>() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); return false; }
             const int t = (todo & 1) ? 0 : 1;
             if (root_pre<G>(E, g, gs, trees[t], t, S)) {
                 const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
@@ -889,15 +894,15 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                     root_post<G>(E, g, gs, trees[t], t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL));
                     if (tlane<G>() == 0) { gs.roots_todo &= ~(1 << t); gs.n_evals += 1; gs.n_hits += 1; }
                     wave_sync();
-                    continue;
+                    return false;
                 }
                 if (tlane<G>() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = t; }
                 wave_sync();
-                return;
+                return true;
             }
             if (tlane<G>() == 0) gs.roots_todo &= ~(1 << t);
             wave_sync();
-            if (tuni<G>(*E.error)) return;
+            if (tuni<G>(*E.error)) return true;
         } else if (phase == PH_MOVE_BEGIN) {                           // Self_Play.py:82-106 + MCTS.run head (MCTS.py:542-558)
             copy_board<G>(S.board, gs.board);
             wave_sync();
@@ -915,7 +920,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             wave_sync();
         } else if (phase == PH_SIMS) {                                 // MCTS.run loop body (MCTS.py:560-587)
-            if (tuni<G>(gs.sims_done) >= tuni<G>(gs.iter_limit) || (E.stop_search && tuni<G>(gs.sims_done) > 0)) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); continue; }
+            if (tuni<G>(gs.sims_done) >= tuni<G>(gs.iter_limit) || (E.stop_search && tuni<G>(gs.sims_done) > 0)) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); return false; }
             const int t = tuni<G>(gs.runner);
             TreeState& ts = trees[t];
             NodeRef<G> r = node_at(E, g, t, ts.root);
@@ -965,16 +970,16 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                     gs.sims_done += chunk; gs.n_sims += (uint64_t)chunk;
                 }
                 wave_sync();
-                continue;
+                return false;
             }
-            if (tree_only >= E.max_tree_sims) return;                  // bound the launch's tail; resume next wave
+            if (tree_only >= E.max_tree_sims) return true;                  // bound the launch's tail; resume next wave
             tree_only++;
             int node, depth; bool leaf_win = false; int kind;
             const long long ts0 = GAZ_PROF_NOW();
             if (!tuni<G>(gs.fully_visited)) { node = ts.root; depth = 0; kind = 0; }
             else kind = puct_select<G>(E, g, gs, ts, t, S, node, depth, leaf_win);
             GAZ_PROF(1, ts0);
-            if (kind < 0) return;
+            if (kind < 0) return true;
             if (kind == 1) {                                           // terminal leaf: value 1 / 0, visits 1 (MCTS.py:573-575)
                 const long long tb0 = GAZ_PROF_NOW();
                 backup<G>(E, g, t, ts, S.path, depth, leaf_win ? 1.0f : 0.0f, 1u);
@@ -989,7 +994,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                     const long long tc0 = GAZ_PROF_NOW();
                     const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
                     GAZ_PROF(3, tc0);
-                    if (!hit) return;                                  // miss: the evaluator answers in the next launch
+                    if (!hit) return true;                                  // miss: the evaluator answers in the next launch
                     const long long tx0 = GAZ_PROF_NOW();
                     expand_post<G>(E, g, gs, ts, t, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                    reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: consume the cached outputs now
@@ -997,7 +1002,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
                     wave_sync();
                     GAZ_PROF(4, tx0);
                 }
-                if (tuni<G>(*E.error)) return;
+                if (tuni<G>(*E.error)) return true;
                 if (tlane<G>() == 0) { gs.sims_done += 1; gs.n_sims += 1; }
                 wave_sync();
             }
@@ -1006,7 +1011,7 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             move_end<G>(E, g, gs, trees[t], t, S);
             if (tlane<G>() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
             wave_sync();
-            if (E.sync_moves) return;
+            if (E.sync_moves) return true;
         } else if (phase == PH_APPLY) {                                // Self_Play.py:142-157
             int action = (tuni<G>(gs.host_move) >= 0) ? tuni<G>(gs.host_move) : tuni<G>(gs.chosen);
             if (tuni<G>(gs.n_hist) == 0 && tuni<G>(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
@@ -1050,14 +1055,22 @@ template <class G> GAZ_DEV void game_step_body(const DevParams<G>& E, int g, Scr
             }
             wave_sync();
         } else if (phase == PH_RING_WAIT) {                            // hand the finished game to the host ring
-            if (!ring_push<G>(E, g, gs)) return;
-            if (E.sync_moves) return;
+            if (!ring_push<G>(E, g, gs)) return true;
+            if (E.sync_moves) return true;
         } else {                                                       // PH_WAIT_HOST, PH_HALT
-            return;
+            return true;
         }
+        return false;
+    };
+    bool done = false;
+    for (int guard = 0; guard < 100000; ++guard) {
+        if (!done && phase_step()) { fin(); done = true; }
+        if (!ballot(!done)) return;                 // wave-uniform exit: every team of this wavefront has yielded
     }
     set_error(E.error, ERR_LOOP_GUARD);
+    if (!done) fin();
 }
+
 
 // The state machine touches its per-game state (phase, counters, pending request, both tree heads) dozens of times per launch,
 // each one a dependent global-memory access.  Without re-root compaction (where node_at() reads TreeState::half from HBM) the
@@ -1101,15 +1114,16 @@ template <class G> GAZ_DEV void game_step(const DevParams<G>& E, int g, Scratch<
     GameState<G>* gsG = &E.games[g];
     TreeState* tsG = E.trees + (size_t)g * 2;
     if (eval_was_skipped<G>(E, g)) { publish_done<G>(E, g, block_rank, block); return; }      // the request stays pending: same leaf row, evaluated by this wave
-    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG); publish_done<G>(E, g, block_rank, block); return; }
+    if (E.compact) { game_step_body<G>(E, g, S, *gsG, tsG, [&]() { publish_done<G>(E, g, block_rank, block); }); return; }
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.ts[0], &tsG[0]); copy_state_words<G>(&L.ts[1], &tsG[1]);
     wave_sync();
-    game_step_body<G>(E, g, S, L.gs, L.ts);
-    wave_sync();
-    copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(&tsG[0], &L.ts[0]); copy_state_words<G>(&tsG[1], &L.ts[1]);
-    publish_done<G>(E, g, block_rank, block);
-    GAZ_PROF(6, tw0);
+    game_step_body<G>(E, g, S, L.gs, L.ts, [&]() {
+        wave_sync();
+        copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(&tsG[0], &L.ts[0]); copy_state_words<G>(&tsG[1], &L.ts[1]);
+        publish_done<G>(E, g, block_rank, block);
+        GAZ_PROF(6, tw0);
+    });
 }
 
 }  // namespace gaz

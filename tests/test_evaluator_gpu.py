@@ -447,7 +447,7 @@ def test_fused_tree_and_trunk_launch_gives_identical_games(search, monkeypatch):
         got.append({(r["slot"], r["game_seq"]): r for r in eng.drain_finished(8192)})
         eng.close()
     a, b = got
-    assert len(a) > 1600 and set(a) == set(b)
+    assert len(a) > (800 if gumbel else 1600) and set(a) == set(b)
     for k in a:
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
