@@ -468,7 +468,8 @@ template <class G> GAZ_DEV void g_move_end(const DevParams<G>& E, int g, GameSta
     wave_sync();
 }
 
-template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts) {
+// (fin: see puct_core.hpp game_step_body — the game's epilogue runs inside the phase loop, where the game yields)
+template <class G, class Fin> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, Scratch<G>& S, GameState<G>& gs, GumbelState<G>& gu, TreeState& ts, Fin&& fin) {
     using RL = RecLayout<G>;
 
     const long long tp0 = GAZ_PROF_NOW();
@@ -488,7 +489,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
 
     GAZ_PROF(0, tp0);
     int tree_only = 0;
-    for (int guard = 0; guard < 100000; ++guard) {
+    auto phase_step = [&]() -> bool {               // one phase of the state machine; true = the game yields for this launch
         const int phase = tuni<G>(gs.phase);
         if (phase == PH_NEW_GAME) {
             for (int c = tlane<G>(); c < G::BPAD; c += G::TEAM) gs.board[c] = 0;
@@ -498,7 +499,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             }
             wave_sync();
         } else if (phase == PH_ROOT) {
-            if (tuni<G>(gs.roots_todo) == 0) { if (tlane<G>() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); continue; }
+            if (tuni<G>(gs.roots_todo) == 0) { if (tlane<G>() == 0) gs.phase = PH_MOVE_BEGIN; wave_sync(); return false; }
             if (tlane<G>() == 0) gs.move_evals = 0;
             if (g_root_pre<G>(E, g, gs, ts, S)) {
                 const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
@@ -506,15 +507,15 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                     g_write_children<G>(E, g, node_at(E, g, 0, ts.root), S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL), true);
                     if (tlane<G>() == 0) { gs.roots_todo = 0; gs.n_evals += 1; gs.n_hits += 1; }
                     wave_sync();
-                    continue;
+                    return false;
                 }
                 if (tlane<G>() == 0) { gs.pend_kind = PEND_ROOT; gs.pend_tree = 0; }
                 wave_sync();
-                return;
+                return true;
             }
             if (tlane<G>() == 0) gs.roots_todo = 0;
             wave_sync();
-            if (tuni<G>(*E.error)) return;
+            if (tuni<G>(*E.error)) return true;
         } else if (phase == PH_MOVE_BEGIN) {                                   // head of MCTS_Gumbel.run (:570-599)
             copy_board<G>(S.board, gs.board);
             wave_sync();
@@ -550,7 +551,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 wave_sync();
                 const bool go = g_halving<G>(E, gu, r, n_root, S);
                 if (!go) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); }
-                continue;
+                return false;
             }
             const int id = tuni<G>((int)gu.top_ids[tuni<G>(gu.cand)]);
             if (tuni<G>(gu.stage) == 0) {                                          // expand the root child first (not an iteration)
@@ -559,18 +560,18 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 if (tuni<G>(r.child()[id]) == CHILD_NONE) {
                     if (g_expand_pre<G>(E, g, gs, ts, S, ts.root, id, 0)) {
                         const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
-                        if (!hit) return;
+                        if (!hit) return true;
                         g_expand_post<G>(E, g, gs, ts, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                          reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: not an iteration (pend_counts = 0)
                         if (tlane<G>() == 0) { gs.pend_kind = PEND_NONE; gs.n_evals += 1; gs.move_evals += 1; gs.n_hits += 1; }
                         wave_sync();
                     }
-                    if (tuni<G>(*E.error)) return;
+                    if (tuni<G>(*E.error)) return true;
                 }
-                continue;
+                return false;
             }
-            if (tuni<G>(gu.sims_left) <= 0) { if (tlane<G>() == 0) { gu.cand += 1; gu.stage = 0; } wave_sync(); continue; }
-            if (tree_only >= E.max_tree_sims) return;
+            if (tuni<G>(gu.sims_left) <= 0) { if (tlane<G>() == 0) { gu.cand += 1; gu.stage = 0; } wave_sync(); return false; }
+            if (tree_only >= E.max_tree_sims) return true;
             tree_only++;
             // one simulation below root child `id`
             int node = ts.root, depth = 0, slot = id;
@@ -579,7 +580,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             for (;;) {
                 // below the root the record of `node` is already in LDS (staged for its deterministic_selection)
                 const int c = staged ? tuni<G>(NodeRef<G>{reinterpret_cast<uint8_t*>(S.node)}.child()[slot]) : tuni<G>(node_at(E, g, 0, node).child()[slot]);
-                if (depth >= PathCap<G>::V - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return; }
+                if (depth >= PathCap<G>::V - 1) { set_error(E.error, ERR_PATH_OVERFLOW); return true; }
                 if (c == CHILD_NONE) {                                         // expand (node, slot)
                     if (tlane<G>() == 0) gu.pend_counts = 1;
                     wave_sync();
@@ -605,7 +606,7 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 const long long tc0 = GAZ_PROF_NOW();
                 const uint8_t* hit = E.cache ? cache_probe<G>(E, g) : nullptr;
                 GAZ_PROF(3, tc0);
-                if (!hit) return;
+                if (!hit) return true;
                 const long long tx0 = GAZ_PROF_NOW();
                 g_expand_post<G>(E, g, gs, ts, S, reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_POL),
                                  reinterpret_cast<const float*>(hit + CacheLayout<G>::OFF_VAL), true);   // hit: the simulation completes in this launch
@@ -614,14 +615,14 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
                 wave_sync();
                 done = true;
             }
-            if (tuni<G>(*E.error)) return;
+            if (tuni<G>(*E.error)) return true;
             if (done && tlane<G>() == 0) { gu.sims_left -= 1; gu.cur_iter += 1; gs.n_sims += 1; }
             wave_sync();
         } else if (phase == PH_MOVE_END) {
             g_move_end<G>(E, g, gs, gu, ts, S);
             if (tlane<G>() == 0) gs.phase = E.sync_moves ? PH_WAIT_HOST : PH_APPLY;
             wave_sync();
-            if (E.sync_moves) return;
+            if (E.sync_moves) return true;
         } else if (phase == PH_APPLY) {                                        // Self_Play.py:142-157, new tree every move (:151-153)
             int action = (tuni<G>(gs.host_move) >= 0) ? tuni<G>(gs.host_move) : tuni<G>(gs.chosen);
             if (tuni<G>(gs.n_hist) == 0 && tuni<G>(gs.host_move) < 0) action = opening_override<G>(E, g, gs, action);
@@ -655,14 +656,22 @@ template <class G> GAZ_DEV void g_game_step_body(const DevParams<G>& E, int g, S
             }
             wave_sync();
         } else if (phase == PH_RING_WAIT) {
-            if (!ring_push<G>(E, g, gs)) return;
-            if (E.sync_moves) return;
+            if (!ring_push<G>(E, g, gs)) return true;
+            if (E.sync_moves) return true;
         } else {
-            return;
+            return true;
         }
+        return false;
+    };
+    bool yielded = false;
+    for (int guard = 0; guard < 100000; ++guard) {
+        if (!yielded && phase_step()) { fin(); yielded = true; }
+        if (!ballot(!yielded)) return;              // wave-uniform exit: every team of this wavefront has yielded
     }
     set_error(E.error, ERR_LOOP_GUARD);
+    if (!yielded) fin();
 }
+
 
 // The state machine reads and writes its per-game state (phase, counters, candidate list ...) dozens of times per launch, each
 // one a dependent global-memory access.  The launch works on an LDS copy instead: one coalesced load on entry, one store on exit.
@@ -676,11 +685,12 @@ template <class G> GAZ_DEV void g_game_step(const DevParams<G>& E, int g, Scratc
     const long long tw0 = GAZ_PROF_NOW();
     copy_state_words<G>(&L.gs, gsG); copy_state_words<G>(&L.gu, guG); copy_state_words<G>(&L.ts, tsG);
     wave_sync();
-    g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts);
-    wave_sync();
-    copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(guG, &L.gu); copy_state_words<G>(tsG, &L.ts);
-    publish_done<G>(E, g, block_rank, block);
-    GAZ_PROF(6, tw0);
+    g_game_step_body<G>(E, g, S, L.gs, L.gu, L.ts, [&]() {
+        wave_sync();
+        copy_state_words<G>(gsG, &L.gs); copy_state_words<G>(guG, &L.gu); copy_state_words<G>(tsG, &L.ts);
+        publish_done<G>(E, g, block_rank, block);
+        GAZ_PROF(6, tw0);
+    });
 }
 
 }  // namespace gaz
