@@ -603,7 +603,12 @@ template <class G> struct EngineT : gaz_engine {
                 if (eval->plan_uses_queue(plan)) {   // the trunk workgroups take queue entries: the tree blocks rank their games as they finish
                     typedef typename PuctVariant<G>::type GPq;
                     static const bool gumbel_teams = !(getenv("GAZ_FUSE_GUMBEL_TEAMS") && atoi(getenv("GAZ_FUSE_GUMBEL_TEAMS")) == 0);
-                    const int gpb = 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
+                    // games per tree block = rounds x (4 waves x games per wavefront); rounds: measured, see DESIGN (GAZ_FUSE_TREE_ROUNDS overrides)
+                    static const int rounds_env = getenv("GAZ_FUSE_TREE_ROUNDS") ? atoi(getenv("GAZ_FUSE_TREE_ROUNDS")) : 0;
+                    // measured on one box (tools/sweep_rounds.sh): PUCT 1 round 56.6 k positions/s, 2 rounds 54.6 k, 4: 53.8 k; Gumbel (8192 games: every slot
+                    // starts as a tree block) 1: 314 k, 2: 319 k, 4: 321 k, 8: 317 k
+                    const int rounds = rounds_env > 0 ? rounds_env : (cfg.search == GAZ_SEARCH_GUMBEL ? 4 : 1);
+                    const int gpb = rounds * 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
                     Ef.done_queue = d_queue; Ef.queue_gpb = gpb; Ef.queue_nfull = n_eff / gpb; Ef.queue_rem = n_eff % gpb;
                 }
                 const bool launched = cfg.search == GAZ_SEARCH_GUMBEL ? launch_wave_trunk_c4_gumbel(stream, &Ef, 0, n_eff, plan) : launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);

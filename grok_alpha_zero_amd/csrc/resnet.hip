@@ -1219,11 +1219,16 @@ template <class GP, class LOCAL, bool GUMBEL> __device__ GAZ_TREE_ROLE_ATTR void
         if (threadIdx.x == 0) *rank = 0;
         __syncthreads();
     }
+    // A tree block steps queue_gpb games in rounds of NT (completion queue only; otherwise one round): fewer, longer-lived tree blocks hold
+    // fewer of the launch's slots, so more trunk workgroups are resident from the start — and with the queue they find finished games at once.
     const int w = threadIdx.x >> 6, t = team_in_wave<GP>(), i = w * PER + t;
-    const int g = g0 + ((int)blockIdx.x * (TR_THREADS / WAVE) + w) * PER + t;
-    if (g < g1) {
-        if constexpr (GUMBEL) g_game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
-        else game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
+    const int per_block = E.done_queue ? E.queue_gpb : NT;
+    for (int r = 0; r * NT < per_block; ++r) {
+        const int g = g0 + (int)blockIdx.x * per_block + r * NT + w * PER + t;
+        if (g < g1) {
+            if constexpr (GUMBEL) g_game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
+            else game_step<GP>(E, g, S[i], L[i], rank, (int)blockIdx.x);
+        }
     }
 }
 
@@ -1260,7 +1265,7 @@ bool launch_wave_trunk_c4_gumbel(hipStream_t s, const void* dev_params, int g0, 
     const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
     const DevParams<Game<GAME_C4>>& E = *static_cast<const DevParams<Game<GAME_C4>>*>(dev_params);
     static const bool teams = !(getenv("GAZ_FUSE_GUMBEL_TEAMS") && atoi(getenv("GAZ_FUSE_GUMBEL_TEAMS")) == 0);
-    const int per_block = (TR_THREADS / WAVE) * (teams ? WAVE / GP4::TEAM : 1);
+    const int per_block = E.done_queue ? E.queue_gpb : (TR_THREADS / WAVE) * (teams ? WAVE / GP4::TEAM : 1);
     const int n_tree = (g1 - g0 + per_block - 1) / per_block;
     const bool skip = P.args.perm && P.args.perm_small;
     if (!P.mix || !skip) return false;              // only the headline trunk variant is built for this launch
@@ -1274,7 +1279,8 @@ bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1,
     const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
     const DevParams<GP4>& E = *static_cast<const DevParams<GP4>*>(dev_params);
     constexpr int GAMES_PER_BLOCK = (TR_THREADS / WAVE) * (WAVE / GP4::TEAM);
-    const int n_tree = (g1 - g0 + GAMES_PER_BLOCK - 1) / GAMES_PER_BLOCK;
+    const int per_block = E.done_queue ? E.queue_gpb : GAMES_PER_BLOCK;
+    const int n_tree = (g1 - g0 + per_block - 1) / per_block;
     const bool skip = P.args.perm && P.args.perm_small;       // both tile shapes carry an edge-tile permutation (checked by the evaluator)
     if (P.mix && skip) hipLaunchKernelGGL((k_wave_trunk<true, true>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
     else if (P.mix) hipLaunchKernelGGL((k_wave_trunk<true, false>), dim3(n_tree + P.nwg), dim3(TR_THREADS), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
