@@ -786,6 +786,7 @@ struct GenericEvaluator : Evaluator {
     bool trunk = true, trunk_m16 = true; bf16_t* trunk_w = nullptr; float* trunk_prm = nullptr;      // ... or k_block0 + ONE k_trunk launch for blocks 1.. (GAZ_TRUNK=0: per block)
     // ... or block 0 INSIDE that launch (trunk.hpp B0; GAZ_BLOCK0_IN_TRUNK=0: k_block0 ahead of it): block 0's 29 slices + the blocks' 18 each
     bool block0_in_trunk = true; bf16_t* trunk_w0 = nullptr; float* trunk_prm0 = nullptr;
+    bool stem_in_trunk_ok = true;
     bf16_t* stem_frag = nullptr;
 
     ~GenericEvaluator() override {
@@ -951,7 +952,11 @@ struct GenericEvaluator : Evaluator {
         StemGenArgs st; memset(&st, 0, sizeof(st));
         st.in = in; st.w = g("stem.w"); st.scale = g("stem.scale"); st.shift = g("stem.shift"); st.scaleB = g("block0.bn1.scale"); st.shiftB = g("block0.bn1.shift");
         st.out1 = X0; st.out2 = A0; st.M = M; st.H = H; st.W = W; st.CIN = C; st.COUT = SC; st.K = gomoku ? 3 : 5; st.act = gomoku ? NACT_RELU : NACT_GELU;
-        if (gomoku) {
+        const bool fuse = gomoku && fused && blocks > 1;
+        // round 3: the stem inside the one trunk launch too (trunk.hpp S0): no stem kernel, no 256-channel stem tensor.  GAZ_STEM_IN_TRUNK=0 -> k_stem_mfma
+        const bool stem_in_trunk = fuse && stem_in_trunk_ok && block0_in_trunk && trunk && trunk_m16 && trunk_w0 && HW <= 256;
+        if (stem_in_trunk) {
+        } else if (gomoku) {
             StemMArgs sm; memset(&sm, 0, sizeof(sm)); sm.in = in; sm.wfrag = reinterpret_cast<const uint4*>(stem_frag); sm.shift = g("stem.shift");
             sm.out = X0; sm.scaleB = g("block0.bn1.scale"); sm.shiftB = g("block0.bn1.shift"); sm.out2 = A0; sm.M = M; sm.H = H; sm.W = W;
             const int tiles = (M + 31) / 32;
@@ -968,7 +973,6 @@ struct GenericEvaluator : Evaluator {
         hipEvent_t e0 = 0, e1 = 0;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); tev.push_back(e0); tev.push_back(e1); hipEventRecord(e0, s); }
         trunk_convs = 0; fused_blocks = 0; one_launch = false;
-        const bool fuse = gomoku && fused && blocks > 1;
         bf16_t* cur = X;                            // raw trunk activation after the last block
         for (int i = 0; i < blocks; ++i) {
             const std::string b = "block" + std::to_string(i), nb = "block" + std::to_string(i + 1);
@@ -976,7 +980,9 @@ struct GenericEvaluator : Evaluator {
             if (fuse && first && block0_in_trunk && trunk && trunk_m16 && trunk_w0 && HW <= 256) {      // the whole trunk, block 0 included, in one launch
                 TrunkArgs t; memset(&t, 0, sizeof(t));
                 t.x0 = X0; t.prm0 = trunk_prm0; t.xout = Hh; t.w = trunk_w0; t.prm = trunk_prm; t.M = M; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
-                hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), dim3(n), dim3(512), trunk_lds_bytes(256), s, t);
+                t.planes = in; t.stem_frag = reinterpret_cast<const uint4*>(stem_frag); t.stem_shift = g("stem.shift");
+                if (stem_in_trunk) hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8, true, 0, true>), dim3(n), dim3(512), trunk_lds_bytes_s0(), s, t);
+                else hipLaunchKernelGGL((k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), dim3(n), dim3(512), trunk_lds_bytes(256), s, t);
                 cur = Hh; fused_blocks += blocks; block0_fused = true; one_launch = true;
                 break;
             }
@@ -1123,6 +1129,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     e->trunk_m16 = !(getenv("GAZ_TRUNK_M16") && atoi(getenv("GAZ_TRUNK_M16")) == 0);
     e->block0_in_trunk = !(getenv("GAZ_BLOCK0_IN_TRUNK") && atoi(getenv("GAZ_BLOCK0_IN_TRUNK")) == 0);
+    e->stem_in_trunk_ok = !(getenv("GAZ_STEM_IN_TRUNK") && atoi(getenv("GAZ_STEM_IN_TRUNK")) == 0);
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);
@@ -1137,6 +1144,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     hipFuncSetAttribute((const void*)(k_trunk<4, 2, 4, 2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256, true));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256));
     hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes(256));
+    hipFuncSetAttribute((const void*)(k_trunk<2, 2, 8, 2, false, false, false, true, 8, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes_s0());
     hipFuncSetAttribute((const void*)(k_resblock3<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rb3_lds_bytes<4>());
     hipFuncSetAttribute((const void*)(k_conv3x3<128, 128, 256, 4, 2, 2, 2, 1, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)(k_conv3x3<256, 128, 128, 2, 2, 2, 2, 4, 1, 0, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -106,8 +106,13 @@ template <bool M16> __device__ __forceinline__ int swz_inv(int sp, int row) { re
 // re-reads exactly the 8-byte groups it wrote one block earlier), which halves the LDS footprint: the 256-row tile of a Gomoku
 // board (TM = 4: wave = 128 cells x 64 channels, half the weight bytes per MFMA of the TM = 2 shape) still fits twice on a CU.
 // NW = waves per workgroup (4; 8 for the 256-row Gomoku tile: WM = 4 waves down the cells, one workgroup per CU with both images in LDS).
-template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
-__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, const int tile_rows, const uint8_t* perm = nullptr, const unsigned boffp = 0) {
+// S0 (round 3, with B0): the 256-channel STEM of the Gomoku network (Gomoku/Build_Model.py:21-24: Conv3x3 2 -> 256, BN, ReLU; k_stem_mfma's
+// arithmetic) is computed inside this launch as well, half by half, straight into the operand image — no stem kernel, no 236-MB stem tensor
+// written and read back four times, and the launch depends on nothing but the int8 planes: it can share a launch with the tree step.
+template <int TM, int WN, int RING, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0, bool S0 = false>
+__device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, const int tile_rows, const uint8_t* perm = nullptr, const unsigned boffp = 0) {
+    static_assert(!S0 || (B0 && TM == 2 && WN == 2), "in-kernel 256-channel stem: block-0 variant, 64 x 64 wave tile");
+    long m0 = m0_;                                  // S0 + completion queue: replaced by the queue entry's game below
     static_assert(!B0 || (M16 && !STEM && !HEADS && !RESG), "block 0 inside the launch: 16x16x32 build with both images in LDS");
     static_assert(SKIPSET == 0 || (STEM && HEADS && M16), "board offsets in the image: only where the kernel itself maps image rows to global rows");
     constexpr int SL0 = B0 ? 29 : 0;                // weight slices of block 0 ahead of the regular blocks' 18 each
@@ -167,7 +172,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             __builtin_amdgcn_global_load_lds((const void*)(x04 + gr * (2 * SLOTS) + half * SLOTS + swz_inv<M16>(sp, lr)), (lds_ptr_t)(As + base), 16, 0, 0);
         }
     };
-    if (B0) load_x0_half(0);
+    if (B0 && !S0) load_x0_half(0);
     if (!STEM && !B0) {
     // ---- raw rows of the tile -> Xs by LDS-DMA, swizzled through the source address (image row q <-> global row m0 + q)
     for (int base = wave * 64; base < n_slots; base += THREADS) {
@@ -210,7 +215,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         return row * 256 + (swz_slot<M16>(cslot, row) << 4) + lhi * 8;
     };
     // fused launch: "this workgroup's wait ran out" (Xt[0]), workgroup-uniform after the barrier
-    if (STEM && (a.ready || a.queue)) {             // wait for the tree teams of this tile's boards (see TrunkArgs::ready / queue), for a bounded time
+    if ((STEM || S0) && (a.ready || a.queue)) {     // wait for the tree teams of this tile's boards (see TrunkArgs::ready / queue), for a bounded time
         if (tid == 0) Xt[0] = 0;                    // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
         const long b = m0 / HW + tid;               // board of the batch = done flag index, or queue entry
         if (tid < tile_rows / HW) {
@@ -218,7 +223,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
             if (b * HW < a.M) {
                 bool fail = a.test_fault_mod && blockIdx.x % a.test_fault_mod == 1;
                 auto arrived = [&]() -> bool {
-                    if (SKIPSET != 0 && a.queue) {
+                    if ((SKIPSET != 0 || S0) && a.queue) {
                         const unsigned long long v = __hip_atomic_load(a.queue + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         game = (int)(unsigned)v;
                         return (unsigned)(v >> 32) == a.epoch;
@@ -241,12 +246,13 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
         asm volatile("" ::: "memory");              // no plane load may be hoisted above the poll
     }
     __syncthreads();                                // Xs, block 0's parameters and the zero row landed
-    if (STEM && (a.ready || a.queue)) {
+    if ((STEM || S0) && (a.ready || a.queue)) {
         if (__builtin_amdgcn_readfirstlane(Xt[0])) {     // (scalar branch) leave the tile out: no board of it is marked, their games re-request (DevParams::eval_done)
             if (tid == 0 && a.fuse_fault) atomicAdd(a.fuse_fault, 1);
             return;
         }
         if (tid < tile_rows / HW && Xt[1 + tid] >= 0 && a.eval_done) a.eval_done[Xt[1 + tid]] = a.epoch;      // this launch evaluates these games (read by the NEXT launch's tree step)
+        if (S0 && a.queue) m0 = (long)__builtin_amdgcn_readfirstlane(Xt[1]) * HW;      // one board per tile: the queue entry's game IS the tile's global row base
     }
     // (behind the barrier: with the completion queue, which games — hence which rows are valid — is only known now)
 #pragma unroll
@@ -520,11 +526,79 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                 As[i] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         };
+        // S0: this lane's stem activations (taps x 2 planes of cells lrow[0], lrow[1]; exact small integers as bf16) are the same for all four
+        // half-image passes and for both waves of a wave row: made once, parked in LDS behind the parameter sets.  K = 18 padded to two k-steps
+        // of 16: k = tap * 2 + plane, lane half lhi holds k-groups of 8 (k_stem_mfma's operand layout, CIN = 2).
+        uint4* Cf = reinterpret_cast<uint4*>(reinterpret_cast<char*>(const_cast<int*>(Xt)) + TR_XTRA);    // [wave row][tm][k-step][lane]
+        if constexpr (S0) {
+            const unsigned short* in16 = reinterpret_cast<const unsigned short*>(a.planes);
+            if (wn == 0) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    int cell_; long gr;
+                    const bool rok = locate(lrow[tm], cell_, gr);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        int pl[8];
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const int tap = ks * 8 + lhi * 4 + h;
+                            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                            int packed = 0;
+                            if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u))
+                                packed = (a.ready || a.queue) ? (int)__hip_atomic_load(in16 + (gr + dy * a.W + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : (int)in16[gr + dy * a.W + dx];
+                            pl[h * 2] = (int)(int8_t)(packed & 0xFF); pl[h * 2 + 1] = (int)(int8_t)((packed >> 8) & 0xFF);
+                        }
+                        Cf[((wm * TM + tm) * 2 + ks) * 64 + lane] = make_uint4(s8x2_to_bf16x2(pl[0], pl[1]), s8x2_to_bf16x2(pl[2], pl[3]), s8x2_to_bf16x2(pl[4], pl[5]), s8x2_to_bf16x2(pl[6], pl[7]));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // one 128-channel half of the stem output over the operand image: raw (the projection's operand) or pre-activated with block 0's bn1
+        // (conv1's operand) — bit for bit what k_stem_mfma writes and load_x0_half / preact_half then bring in
+        auto stem_half = [&](const int half, const bool preact) {
+            uint4 sw[4][TN];                        // weight fragments: k-steps hi0, hi1, lo0, lo1 (stem_fragments: [k-step][k-half][256 channels])
+#pragma unroll
+            for (int ks2 = 0; ks2 < 4; ++ks2)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) sw[ks2][tn] = a.stem_frag[(ks2 * 2 + lhi) * 256 + half * 128 + wn * (32 * TN) + tn * 32 + l31];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const uint4 c0 = Cf[((wm * TM + tm) * 2 + 0) * 64 + lane], c1 = Cf[((wm * TM + tm) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    f32x16 sacc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 4; ++ks2)
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&sw[ks2][tn]), *reinterpret_cast<const bf16x8*>((ks2 & 1) ? &c1 : &c0), sacc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = half * 128 + ((wn * TN + tn) * 4 + j) * 8 + 4 * lhi;       // channel of the 256
+                        const float4 sh = *reinterpret_cast<const float4*>(a.stem_shift + c);
+                        const float v0 = fmaxf(sacc[4 * j + 0] + sh.x, 0.0f), v1 = fmaxf(sacc[4 * j + 1] + sh.y, 0.0f);
+                        const float v2 = fmaxf(sacc[4 * j + 2] + sh.z, 0.0f), v3 = fmaxf(sacc[4 * j + 3] + sh.w, 0.0f);
+                        uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+                        if (preact) {
+                            const float4 sc = *reinterpret_cast<const float4*>(&Ps[c]);
+                            const float4 t4 = *reinterpret_cast<const float4*>(&Ps[256 + c]);
+                            const float a0 = fmaxf(__uint_as_float(xn.x << 16) * sc.x + t4.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * sc.y + t4.y, 0.0f);
+                            const float a2 = fmaxf(__uint_as_float(xn.y << 16) * sc.z + t4.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * sc.w + t4.w, 0.0f);
+                            xn = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+                        }
+                        *reinterpret_cast<uint2*>(Ab + img_off(tm, tn, j)) = xn;
+                    }
+                }
+            }
+        };
         // five passes over the operand image, ONE copy of the tap loop: conv1 over the pre-activated low / high input half, conv2 over
         // h, the skip path's 1x1 projection (centre tap) over the raw low / high half
 #pragma unroll 1
         for (int ph = 0; ph < 5; ++ph) {
             if (ph > 0) __syncthreads();            // every wave is done with the previous image
+            if (S0 && ph != 2) { stem_half(ph == 0 || ph == 3 ? 0 : 1, ph < 2); }
             if (ph == 2) {                          // block 0's bn1 vectors (parameter set 0) are free: the first regular block's parameters
                 if (tid < TR_PRM / 4) Ps4[tid] = prm4[tid];
 #pragma unroll
@@ -539,11 +613,11 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
                         *reinterpret_cast<uint2*>(Ab + off16(ct, t)) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
                     }
                 }
-            } else if (ph > 0) {
+            } else if (ph > 0 && !S0) {
                 load_x0_half(ph == 3 ? 0 : 1);      // ph 1: high half; ph 3 / 4: the raw stem output again, low / high
                 __syncthreads();
             }
-            if (ph < 2) { preact_half(ph); }
+            if (ph < 2 && !S0) { preact_half(ph); }
             __syncthreads();
             if (ph == 0 || ph == 2) zero_acc16();
             conv_taps(ph < 3 ? 9 * ph : 24 + ph, ph < 3 ? 0 : 4, ph < 3 ? 9 : 1);
@@ -874,10 +948,11 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0, co
     TR_STAMP(63);
 }
 
-template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0>
+template <int TM, int WN, int RING, int OCC, bool STEM, bool HEADS, bool RESG = false, bool M16 = false, int NW = 4, bool B0 = false, int SKIPSET = 0, bool S0 = false>
 __global__ __launch_bounds__(64 * NW, OCC) void k_trunk(TrunkArgs a) {
-    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0, SKIPSET>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIPSET ? a.perm : nullptr, a.boff);
+    trunk_tile<TM, WN, RING, STEM, HEADS, RESG, M16, NW, B0, SKIPSET, S0>(a, (long)blockIdx.x * a.tile_rows, a.tile_rows, SKIPSET ? a.perm : nullptr, a.boff);
 }
+constexpr size_t trunk_lds_bytes_s0() { return trunk_lds_bytes(256) + 4 * 2 * 2 * 64 * 16; }      // + the parked stem activations (Cf)
 
 // Two tile shapes in one launch.  Workgroups are dispatched in index order and a CU holds two, so the batch is processed in rounds of
 // 2 x CUs tiles; 4096 Connect4 boards in 3-board tiles are 1366 tiles = 2.67 rounds, the third one two thirds full and as long as

@@ -580,3 +580,30 @@ def test_tictactoe_evaluator_matches_bf16_faithful_reference_per_layer(blocks, a
         assert m["p_feat_rel_max"] <= 1e-2 and m["v_feat_rel_max"] <= 1e-2 and m["p_feat_mean"] <= 2e-4 and m["v_feat_mean"] <= 2e-4, m
         # measured on the MI355X (block 0 active, 300 positions): features 4.5e-3 rel (one flipped bf16 rounding), logits 2.8e-3, value 1.6e-3 — ~2x margin
         assert m["pol_max"] <= (6e-3 if logits_mode else 2e-3) and m["value_max"] <= 4e-3, m
+
+
+@pytest.mark.parametrize("blocks,n", [(2, 5), (10, 300), (10, 2048)])
+def test_gomoku_stem_inside_the_trunk_launch_is_bit_identical(blocks, n, monkeypatch):
+    """Round 3 (trunk.hpp S0): the Gomoku network's 256-channel stem (Gomoku/Build_Model.py:21-24) computed inside the one trunk launch, half
+    by half, straight into block 0's operand image — against the stem kernel + the launch that reads its output back (GAZ_STEM_IN_TRUNK=0):
+    same arithmetic in the same order (k_stem_mfma's hi + lo split on v_mfma_f32_32x32x16_bf16, ReLU, bf16, block 0's pre-activation from the
+    rounded value), so policy, value and head features must be bit-identical, ragged batches included."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    net = NETS["Gomoku"](blocks, seed=3).eval().randomize_bn(5)
+    w = net.export_engine_weights()
+    rng = np.random.default_rng(blocks + n)
+    who = rng.integers(0, 3, size=(n, 15, 15))
+    x = np.zeros((n, 15, 15, 2), np.int8); x[..., 0] = who == 1; x[..., 1] = who == 2
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GAZ_STEM_IN_TRUNK", flag)
+        eng = SelfPlayEngine("Gomoku", max(n, 8), 8, 10, 2, 2, 4.5, 0.05, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks, net_filters=128, ring_capacity=0)
+        eng.load_weights(w)
+        pol, val, _ = eng.evaluate(x)
+        pf, vf = eng.head_features(n)
+        eng.close()
+        out.append((pol, val, pf, vf))
+    for a, b, name in zip(out[0], out[1], ("policy", "value", "p_feat", "v_feat")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][0].sum(1) - 1).max() < 1e-4
