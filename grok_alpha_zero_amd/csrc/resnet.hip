@@ -953,7 +953,11 @@ struct GenericEvaluator : Evaluator {
         st.in = in; st.w = g("stem.w"); st.scale = g("stem.scale"); st.shift = g("stem.shift"); st.scaleB = g("block0.bn1.scale"); st.shiftB = g("block0.bn1.shift");
         st.out1 = X0; st.out2 = A0; st.M = M; st.H = H; st.W = W; st.CIN = C; st.COUT = SC; st.K = gomoku ? 3 : 5; st.act = gomoku ? NACT_RELU : NACT_GELU;
         const bool fuse = gomoku && fused && blocks > 1;
-        // round 3: the stem inside the one trunk launch too (trunk.hpp S0): no stem kernel, no 256-channel stem tensor.  GAZ_STEM_IN_TRUNK=0 -> k_stem_mfma
+        // round 3: the stem inside the one trunk launch too (trunk.hpp S0; GAZ_STEM_IN_TRUNK=1): no stem kernel, no 256-channel stem tensor,
+        // bit-identical outputs (tests/test_evaluator_gpu.py) — and measured SLOWER on its own: with one 512-thread workgroup per CU nothing
+        // overlaps the four half-image stem passes (trunk launch 2298 -> 2444 us per 2048 positions against the 86 us of k_stem_mfma it
+        // replaces: evaluator pass 2702 -> 2762 us, gpurun_out r03 gmk1 / gmk2).  Kept as an opt-in: it is what lets the launch depend on
+        // nothing but the int8 planes, i.e. what a fused tree + trunk launch for Gomoku needs.
         const bool stem_in_trunk = fuse && stem_in_trunk_ok && block0_in_trunk && trunk && trunk_m16 && trunk_w0 && HW <= 256;
         if (stem_in_trunk) {
         } else if (gomoku) {
@@ -1129,7 +1133,7 @@ static Evaluator* make_generic_evaluator(const gaz_engine_config& cfg, int H, in
     e->trunk = !(getenv("GAZ_TRUNK") && atoi(getenv("GAZ_TRUNK")) == 0);
     e->trunk_m16 = !(getenv("GAZ_TRUNK_M16") && atoi(getenv("GAZ_TRUNK_M16")) == 0);
     e->block0_in_trunk = !(getenv("GAZ_BLOCK0_IN_TRUNK") && atoi(getenv("GAZ_BLOCK0_IN_TRUNK")) == 0);
-    e->stem_in_trunk_ok = !(getenv("GAZ_STEM_IN_TRUNK") && atoi(getenv("GAZ_STEM_IN_TRUNK")) == 0);
+    e->stem_in_trunk_ok = getenv("GAZ_STEM_IN_TRUNK") && atoi(getenv("GAZ_STEM_IN_TRUNK")) != 0;
     { hipDeviceProp_t pr; int dev = 0; hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) e->n_cus = pr.multiProcessorCount; }
     const size_t M = (size_t)cfg.n_games * e->HW, SC = gomoku ? 256 : 128, F = e->F, n = cfg.n_games;
     e->X0 = e->dalloc<bf16_t>(M * SC); e->A0 = e->dalloc<bf16_t>(M * SC); e->X = e->dalloc<bf16_t>(M * F); e->Aa = e->dalloc<bf16_t>(M * F);

@@ -585,7 +585,8 @@ def test_tictactoe_evaluator_matches_bf16_faithful_reference_per_layer(blocks, a
 @pytest.mark.parametrize("blocks,n", [(2, 5), (10, 300), (10, 2048)])
 def test_gomoku_stem_inside_the_trunk_launch_is_bit_identical(blocks, n, monkeypatch):
     """Round 3 (trunk.hpp S0): the Gomoku network's 256-channel stem (Gomoku/Build_Model.py:21-24) computed inside the one trunk launch, half
-    by half, straight into block 0's operand image — against the stem kernel + the launch that reads its output back (GAZ_STEM_IN_TRUNK=0):
+    by half, straight into block 0's operand image (opt-in, GAZ_STEM_IN_TRUNK=1: measured slower on its own, see resnet.hip) — against the
+    stem kernel + the launch that reads its output back (the default):
     same arithmetic in the same order (k_stem_mfma's hi + lo split on v_mfma_f32_32x32x16_bf16, ReLU, bf16, block 0's pre-activation from the
     rounded value), so policy, value and head features must be bit-identical, ragged batches included."""
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
