@@ -259,6 +259,25 @@ def random_histories(game, n, rng, max_ply):
     return out
 
 
+def selfplay_histories(make_hash_engine, G, rng):
+    """G action histories drawn from the STATIONARY distribution of continuous self-play — the position a slot is in at a random moment — for
+    bench.py's staggered start: G complete games are played by the engine itself with the synthetic hash evaluator (same search, same
+    parameters; a fraction of a second), a game is picked with probability proportional to its length and cut at a uniformly random ply
+    (P(ply = p) ~ #{games longer than p}).  MCTS-played positions, unlike random playouts, have the tactical structure (few immediate wins
+    left standing) that decides how many simulations of a move need the evaluator."""
+    e = make_hash_engine()
+    recs = []
+    for _ in range(4000):
+        e.run_waves(256)
+        recs += e.drain_finished(G)
+        if len(recs) >= G:
+            break
+    e.close()
+    T = np.array([r["T"] for r in recs], np.float64)
+    pick = rng.choice(len(recs), size=G, p=T / T.sum())
+    return [[int(a) for a in recs[i]["actions"][: int(rng.integers(0, recs[i]["T"]))]] for i in pick]
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -309,8 +328,13 @@ def main():
             if args.stagger:
                 # steady state from the first timed wave: every slot starts its first game at a random ply of a
                 # random legal playout — the same positions on every run (seeded by the global slot) — instead of all 4096 at ply 0 in lockstep
-                span = {"Connect4": 24, "Gomoku": 60}.get(game, 4)
-                hs = random_histories(game, G, np.random.default_rng(977 + rank), span)
+                rs = np.random.default_rng(977 + rank)
+                if game == "Connect4" and not emu:
+                    hs = selfplay_histories(lambda: SelfPlayEngine(game, G, n_sims, max_actions, ef, es, cpuct, alpha, seed=4321, slot_offset=rank * G, device=local,
+                                                                   evaluator=EVAL_HASH, hash_salt=11, ring_capacity=G, games_budget=G,
+                                                                   search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm, c_visit=50.0, c_scale=1.0), G, rs)
+                else:                               # Gomoku: a game is 150 plies x 400 waves — random legal playouts of 0 .. 60 plies instead
+                    hs = random_histories(game, G, rs, {"Gomoku": 60}.get(game, 4))
                 for slot, h in enumerate(hs):
                     if h:
                         e.set_position(slot, h)
@@ -449,8 +473,11 @@ def main():
                        config=dict(workload=f"{label}, {G} concurrent games/GPU, {sims} sims/move (MCTS.run iteration_limit), "
                                             f"{blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
                                    games_per_gpu=G, sims_per_move=sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
-                                   start=("every slot's first game starts at a random ply of a seeded random playout (games out of step from the first timed wave: "
-                                          "steady state); later games start at ply 0 as they restart on device") if args.stagger else "all games at ply 0",
+                                   start=(("every slot's first game starts at a position drawn from the stationary distribution of continuous self-play: complete games played by "
+                                           "the engine with the synthetic hash evaluator, picked in proportion to their length, cut at a uniform ply"
+                                           if (game == "Connect4" and not emu) else "every slot's first game starts at a random ply (0 .. 60) of a seeded random legal playout") +
+                                          " — games out of step from the first timed wave (steady state); later games start at ply 0 as they restart on device")
+                                   if args.stagger else "all games at ply 0",
                                    parallelism=f"games sharded x{world} (rank r owns global slots [r G, (r + 1) G)), counters all-reduced"),
                        detail=dict(positions=positions, positions_per_rank=[int(x) for x in per_rank],
                                    positions_per_rank_min=int(per_rank.min()), positions_per_rank_max=int(per_rank.max()),

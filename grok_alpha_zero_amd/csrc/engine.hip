@@ -515,7 +515,10 @@ template <class G> struct EngineT : gaz_engine {
         // written by k_cache_insert between launches as before.  GAZ_FUSE_CACHE=0 -> separate launches when the cache is on
         static const bool with_cache = !(getenv("GAZ_FUSE_CACHE") && atoi(getenv("GAZ_FUSE_CACHE")) == 0);
         const bool gumbel = cfg.search == GAZ_SEARCH_GUMBEL;
-        if (off || G::ID != GAME_C4 || WAVE / GP::TEAM != 4 || (E.cache && !with_cache) || E.compact || !eval || !eval->supports_split()) return false;
+        // round 3: Gomoku's PUCT search as well (one game per wavefront; compacting trees are fine: a game's state lives in HBM either way).  GAZ_FUSE_GOMOKU=0 -> separate
+        const bool gmk = G::ID == GAME_GMK && !gumbel && !E.cache && !(getenv("GAZ_FUSE_GOMOKU") && atoi(getenv("GAZ_FUSE_GOMOKU")) == 0);
+        const bool c4 = G::ID == GAME_C4 && WAVE / GP::TEAM == 4 && !E.compact && !(E.cache && !with_cache);
+        if (off || !(c4 || gmk) || !eval || !eval->supports_split()) return false;
         // round 3: the Gumbel search too (BASELINE configs[4]; its tree step is 17 % of a wave when launched separately).  GAZ_FUSE_GUMBEL=0 -> separate
         if (gumbel && ((getenv("GAZ_FUSE_GUMBEL") && atoi(getenv("GAZ_FUSE_GUMBEL")) == 0) || E.cache)) return false;
         if (!gumbel && getenv("GAZ_TREE_TEAMS") && atoi(getenv("GAZ_TREE_TEAMS")) == 0) return false;
@@ -607,11 +610,13 @@ template <class G> struct EngineT : gaz_engine {
                     static const int rounds_env = getenv("GAZ_FUSE_TREE_ROUNDS") ? atoi(getenv("GAZ_FUSE_TREE_ROUNDS")) : 0;
                     // measured on one box (tools/sweep_rounds.sh): PUCT 1 round 56.6 k positions/s, 2 rounds 54.6 k, 4: 53.8 k; Gumbel (8192 games: every slot
                     // starts as a tree block) 1: 314 k, 2: 319 k, 4: 321 k, 8: 317 k
-                    const int rounds = rounds_env > 0 ? rounds_env : (cfg.search == GAZ_SEARCH_GUMBEL ? 4 : 1);
-                    const int gpb = rounds * 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
+                    const int rounds = rounds_env > 0 ? rounds_env : (G::ID == GAME_GMK ? 8 : (cfg.search == GAZ_SEARCH_GUMBEL ? 4 : 1));
+                    const int gpb = G::ID == GAME_GMK ? rounds * 8 : rounds * 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
                     Ef.done_queue = d_queue; Ef.queue_gpb = gpb; Ef.queue_nfull = n_eff / gpb; Ef.queue_rem = n_eff % gpb;
                 }
-                const bool launched = cfg.search == GAZ_SEARCH_GUMBEL ? launch_wave_trunk_c4_gumbel(stream, &Ef, 0, n_eff, plan) : launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
+                Ef.handoff_release = G::ID == GAME_GMK;
+                const bool launched = G::ID == GAME_GMK ? launch_wave_trunk_gmk(stream, &Ef, 0, n_eff, plan)
+                                    : cfg.search == GAZ_SEARCH_GUMBEL ? launch_wave_trunk_c4_gumbel(stream, &Ef, 0, n_eff, plan) : launch_wave_trunk_c4(stream, &Ef, 0, n_eff, plan);
                 if (!launched) {                     // no fused kernel for this trunk variant: separate launches, for good
                     fuse_state = 0; --fuse_epoch;
                     return one_wave(with_eval);

@@ -90,6 +90,8 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config& cfg, int H, int W, int
 bool launch_wave_trunk_c4(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
 // the same for the Gumbel search (MCTS_Gumbel.py:562-679) of Connect4: one wavefront per game, four games per tree block.  dev_params: DevParams<Game<GAME_C4>>
 bool launch_wave_trunk_c4_gumbel(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
+// the same for Gomoku's PUCT search: one game per wavefront, eight per tree block and round.  dev_params: DevParams<Game<GAME_GMK>>
+bool launch_wave_trunk_gmk(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan);
 
 inline Evaluator* make_evaluator(const gaz_engine_config& cfg, int H, int W, int C, int A, std::string* err) {
     if (cfg.evaluator == GAZ_EVAL_HASH) return new HashEvaluator(H * W * C, A, cfg.hash_salt);

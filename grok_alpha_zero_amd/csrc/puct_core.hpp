@@ -86,6 +86,7 @@ template <class G> struct DevParams {
     // workgroup sits on a slot waiting for one slow game (rows of an evaluator batch are independent bit for bit, so which tile evaluates a
     // game cannot change its outputs).  No global atomics: a tree block ranks its own games by a counter in LDS, and entry (rank r, block j)
     // sits at r * n_full + min(r, rem) + j — rank-major, so the entries of every block's fastest game come first.  Entry = epoch << 32 | game.
+    int32_t handoff_release;           // 1: the leaf row was written with plain stores -> agent-scope release before the flag / entry (Gomoku: rows not dword-aligned)
     unsigned long long* done_queue;    // [n_games] or null (then done_flag is used)
     int32_t queue_gpb, queue_nfull, queue_rem;   // games per tree block; blocks with that many games; games of the last, partial block
 };
@@ -1088,6 +1089,10 @@ template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g, uint3
 #ifndef GAZ_HOST_EMU
     if (E.done_queue && block_rank) {               // completion queue: this game is the rank-th of its tree block to finish
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (E.handoff_release) {                    // plain row stores: write back this XCD's L2 before the entry can be seen (Guideline 16 R1)
+            if (tlane<G>() == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (tlane<G>() == 0) {
             const int rank = (int)atomic_add(block_rank, 1u);              // LDS
             const int entry = rank * E.queue_nfull + (rank < E.queue_rem ? rank : E.queue_rem) + block;
@@ -1096,6 +1101,10 @@ template <class G> GAZ_DEV void publish_done(const DevParams<G>& E, int g, uint3
         return;
     }
     if (!E.done_flag) return;
+    if (E.handoff_release) {                        // (see above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tlane<G>() == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
     // every store of this wave — the leaf row included — has been acknowledged before the flag is written.  Inline asm with a memory clobber: the
     // compiler may neither sink a row store below it nor hoist the flag store above it (MI355X_MICROARCH.md, Valid forms: write-through payload ->
     // asm vmcnt(0) -> flag), which a relaxed atomic + the waitcnt builtin alone would not forbid.

@@ -946,7 +946,30 @@ struct GenericEvaluator : Evaluator {
     float* g(const std::string& k) { return f32[k]; }
     bool head_features(const float** p, const float** v, int* pr, int* vr) override { *p = pfeat; *v = vfeat; *pr = HW * 8; *vr = HW * 4; return true; }
 
+    // ---- the forward pass in two parts (engine.hip: the fused tree + trunk launch replaces forward_trunk by its own launch of the same kernel)
+    bf16_t* trunk_out = nullptr;                    // raw trunk activation the heads read (set by forward_trunk / the fused launch's plan)
+    bool fuse_heads = false;
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int = 0) override {
+        forward_trunk(s, in, n, timing, 0);
+        forward_heads(s, policy, value, n, 0);
+    }
+    bool fusable() const { return gomoku && fused && blocks > 1 && block0_in_trunk && trunk && trunk_m16 && trunk_w0 && HW <= 256; }
+    bool supports_split() const override { return loaded && fusable(); }
+    TrunkLaunchPlan fused_plan;
+    // the Gomoku trunk launch with the stem inside (trunk.hpp S0): it reads nothing but the int8 planes, so it can share a launch with the tree step
+    const void* trunk_plan(const int8_t* in, int n, int p0, const FuseHandoff& h) override {
+        if (!supports_split() || p0 != 0) return nullptr;
+        TrunkArgs& t = fused_plan.args; memset(&t, 0, sizeof(t));
+        t.prm0 = trunk_prm0; t.xout = Hh; t.w = trunk_w0; t.prm = trunk_prm; t.M = n * HW; t.H = H; t.W = W; t.nblocks = blocks - 1; t.tile_rows = HW;
+        t.planes = in; t.stem_frag = reinterpret_cast<const uint4*>(stem_frag); t.stem_shift = g("stem.shift");
+        t.ready = h.ready; t.epoch = h.epoch; t.eval_done = h.eval_done; t.fuse_fault = h.fuse_fault; t.spin_ticks = h.spin_ticks; t.test_fault_mod = h.test_fault_mod;
+        t.stamps = h.stamps; t.queue = h.queue;
+        fused_plan.nwg = n; fused_plan.mix = 0; fused_plan.lds_bytes = (unsigned)trunk_lds_bytes_s0();
+        trunk_out = Hh; fuse_heads = true;
+        return &fused_plan;
+    }
+    bool plan_uses_queue(const void* plan) const override { return plan && static_cast<const TrunkLaunchPlan*>(plan)->args.queue != nullptr; }
+    void forward_trunk(hipStream_t s, const int8_t* in, int n, bool timing, int) override {
         if (!loaded) return;
         const int M = n * HW, SC = gomoku ? 256 : 128;
         StemGenArgs st; memset(&st, 0, sizeof(st));
@@ -1048,6 +1071,12 @@ struct GenericEvaluator : Evaluator {
             }
         }
         if (timing) hipEventRecord(e1, s);
+        trunk_out = cur; fuse_heads = fuse;
+    }
+    void forward_heads(hipStream_t s, float* policy, float* value, int n, int) override {
+        if (!loaded) return;
+        const int M = n * HW;
+        bf16_t* const cur = trunk_out; const bool fuse = fuse_heads;
         if (gomoku) {
             if (fuse) {                             // both heads' BN + ReLU + Conv3x3 128 -> 32 + BN + ReLU from the raw trunk output
                 Head32Args hh; memset(&hh, 0, sizeof(hh));
@@ -1221,12 +1250,13 @@ typedef TeamGame<GAME_C4> GP4;
 #ifndef GAZ_TREE_ROLE_ATTR
 #define GAZ_TREE_ROLE_ATTR __forceinline__
 #endif
-template <class GP, class LOCAL, bool GUMBEL> __device__ GAZ_TREE_ROLE_ATTR void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
-    constexpr int PER = WAVE / GP::TEAM, NT = (TR_THREADS / WAVE) * PER;
+template <class GP, class LOCAL, bool GUMBEL, int THREADS = TR_THREADS, size_t LDS_BYTES = trunk_lds_bytes(96)>
+__device__ GAZ_TREE_ROLE_ATTR void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
+    constexpr int PER = WAVE / GP::TEAM, NT = (THREADS / WAVE) * PER;
     Scratch<GP>* S = reinterpret_cast<Scratch<GP>*>(lds);
     LOCAL* L = reinterpret_cast<LOCAL*>(S + NT);
     uint32_t* rank = reinterpret_cast<uint32_t*>(L + NT);           // completion queue: how many games of this block have finished (DevParams::done_queue)
-    static_assert(NT * (sizeof(Scratch<GP>) + sizeof(LOCAL)) + 16 <= trunk_lds_bytes(96), "tree scratch must fit the trunk's LDS allocation");
+    static_assert(NT * (sizeof(Scratch<GP>) + sizeof(LOCAL)) + 16 <= LDS_BYTES, "tree scratch must fit the trunk's LDS allocation");
     if (E.done_queue) {
         if (threadIdx.x == 0) *rank = 0;
         __syncthreads();
@@ -1263,6 +1293,37 @@ __device__ __forceinline__ void wave_trunk_body(const DevParams<GP>& E, int g0, 
 
 template <bool MIX, bool SKIP> __global__ __launch_bounds__(TR_THREADS, 2) void k_wave_trunk(DevParams<GP4> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
     wave_trunk_body<MIX, SKIP, GP4, PuctLocal<GP4>, false>(E, g0, g1, n_tree_blocks, a);
+}
+
+// Gomoku (BASELINE configs[3]): one game per wavefront, eight per 512-thread tree block and round; the trunk role is the 8-wave launch with block 0
+// AND the 256-channel stem inside (trunk.hpp S0), one board = one queue entry per workgroup, one workgroup per CU.  The leaf rows of a 15 x 15 x 2
+// board are 450 bytes — not dword-aligned from game to game — so this hand-over uses the release / acquire form (MI355X_MICROARCH.md, Valid
+// forms): the game's wave writes its row with plain stores, waits for them, releases at agent scope (puct_core.hpp publish_done,
+// DevParams::handoff_release) and then writes its queue entry; the workgroup's polling lane acquires before the barrier, the planes are
+// read with plain loads behind it.  A tree step here is hundreds of microseconds, the two fences a few.
+typedef Game<GAME_GMK> GGMK;
+__global__ __launch_bounds__(512, 1) void k_wave_trunk_gmk(DevParams<GGMK> E, int g0, int g1, int n_tree_blocks, TrunkArgs a) {
+    if ((int)blockIdx.x < n_tree_blocks) {
+        extern __shared__ uint4 lds[];
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(size_t)blockIdx.x * 128 + (threadIdx.x >> 6)] = wall_clock64();
+        tree_role<GGMK, PuctLocal<GGMK>, false, 512, trunk_lds_bytes_s0()>(E, g0, g1, lds);
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(size_t)blockIdx.x * 128 + 8 + (threadIdx.x >> 6)] = wall_clock64();
+        return;
+    }
+    const int bid = (int)blockIdx.x - n_tree_blocks;
+    trunk_tile<2, 2, 8, false, false, false, true, 8, true, 0, true>(a, (long)bid * a.tile_rows, a.tile_rows, nullptr, 0);
+}
+
+bool launch_wave_trunk_gmk(hipStream_t s, const void* dev_params, int g0, int g1, const void* plan) {
+    if (!plan || !dev_params) return false;
+    const TrunkLaunchPlan& P = *static_cast<const TrunkLaunchPlan*>(plan);
+    const DevParams<GGMK>& E = *static_cast<const DevParams<GGMK>*>(dev_params);
+    const int per_block = E.done_queue ? E.queue_gpb : 8;
+    const int n_tree = (g1 - g0 + per_block - 1) / per_block;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_wave_trunk_gmk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trunk_lds_bytes_s0()); attr = true; }
+    hipLaunchKernelGGL(k_wave_trunk_gmk, dim3(n_tree + P.nwg), dim3(512), P.lds_bytes, s, E, g0, g1, n_tree, P.args);
+    return true;
 }
 
 // The Gumbel search (MCTS_Gumbel.py:562-679) in the same launch shape.  TEAMS: four games per wavefront (16 games per tree block, as the PUCT

@@ -240,6 +240,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                     }
                 }
                 if (fail) { Xt[0] = 1; game = -1; }
+                else if (S0) {                      // the row was written with plain stores and released (puct_core.hpp publish_done): acquire, so that
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 holds no older copy; the barrier below holds the other waves back
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
             Xt[1 + tid] = game;
         }
@@ -546,7 +550,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                             int packed = 0;
                             if (rok && tap < 9 && ((vmask[tm] >> tap) & 1u))
-                                packed = (a.ready || a.queue) ? (int)__hip_atomic_load(in16 + (gr + dy * a.W + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : (int)in16[gr + dy * a.W + dx];
+                                packed = (int)in16[gr + dy * a.W + dx];       // (fused launch: behind the poller's acquire + the barrier)
                             pl[h * 2] = (int)(int8_t)(packed & 0xFF); pl[h * 2 + 1] = (int)(int8_t)((packed >> 8) & 0xFF);
                         }
                         Cf[((wm * TM + tm) * 2 + ks) * 64 + lane] = make_uint4(s8x2_to_bf16x2(pl[0], pl[1]), s8x2_to_bf16x2(pl[2], pl[3]), s8x2_to_bf16x2(pl[4], pl[5]), s8x2_to_bf16x2(pl[6], pl[7]));

@@ -8,6 +8,7 @@ Evaluator* make_resnet_evaluator(const gaz_engine_config&, int, int, int, int, s
 }
 bool launch_wave_trunk_c4(hipStream_t, const void*, int, int, const void*) { return false; }
 bool launch_wave_trunk_c4_gumbel(hipStream_t, const void*, int, int, const void*) { return false; }
+bool launch_wave_trunk_gmk(hipStream_t, const void*, int, int, const void*) { return false; }
 }
 
 // test hook (tests/test_tile_perm.py): the host-side tile permutation of the trunk kernel's edge tiles

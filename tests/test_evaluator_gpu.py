@@ -608,3 +608,39 @@ def test_gomoku_stem_inside_the_trunk_launch_is_bit_identical(blocks, n, monkeyp
     for a, b, name in zip(out[0], out[1], ("policy", "value", "p_feat", "v_feat")):
         np.testing.assert_array_equal(a, b, err_msg=name)
     assert np.isfinite(out[0][0]).all() and np.abs(out[0][0].sum(1) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("fault", [0, 5])
+def test_gomoku_fused_tree_and_trunk_launch_gives_identical_games(fault):
+    """Round 3: Gomoku's PUCT tree step (one game per wavefront, 64 games per tree block in eight rounds) and the 8-wave trunk launch with block 0
+    and the stem inside as ONE launch (resnet.hip k_wave_trunk_gmk): completion queue, leaf rows handed over with release / acquire (450-byte rows are
+    not dword-aligned).  Scheduling only: finished games equal those of separate launches bit for bit; fault = 5: every fifth trunk workgroup
+    gives up its wait (gaz_engine_debug_fused_fault) for 24 launches — the games must still come out identical and the engine must fall back."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import NETS
+    w = NETS["Gomoku"](2, seed=8).eval().export_engine_weights()
+    got = []
+    for fused in (True, False):
+        eng = SelfPlayEngine("Gomoku", 300, 24, 4, 2, 2, 4.5, 0.05, seed=31, evaluator=EVAL_RESNET, net_blocks=2, net_filters=128, ring_capacity=1024, games_budget=300)
+        eng.load_weights(w)
+        eng.set_fused_wave(fused)
+        eng.run_waves(30); eng.synchronize()
+        assert eng.stats()["fused_wave"] == int(fused)
+        if fused and fault:
+            eng.debug_fused_fault(fault)
+            eng.run_waves(24)
+            st = eng.stats()
+            assert st["fused_faults"] >= 24 and st["fused_wave"] == 0, st
+        for _ in range(60):
+            eng.run_waves(100)
+            if eng.stats()["game_stats"][2] >= 300:
+                break
+        st = eng.stats()
+        assert st["fused_wave"] == int(fused and not fault) and (fault or st["fused_faults"] == 0), st
+        got.append({(r["slot"], r["game_seq"]): r for r in eng.drain_finished(1024)})
+        eng.close()
+    a, b = got
+    assert len(a) == 300 and set(a) == set(b)
+    for k in a:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
