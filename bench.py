@@ -49,7 +49,11 @@ def parse(argv=None):
     ap.add_argument("--ref-convention-leg", type=int, default=-1, help="1: extra leg at int(1.5 * sims) simulations per move, what Self_Play passes for MCTS_iteration_limit = sims (Self_Play.py:99); default on for the connect4 config at N = 1")
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also measure BASELINE configs[4] (Gumbel) and configs[3] (Gomoku) and append them to the line as "
                                                                   "'gumbel' / 'gomoku' objects (default: on for the plain headline command at N = 1)")
-    ap.add_argument("--stagger", type=int, default=1, help="1 (default): every slot's first game starts at a random ply (steady state from the first timed wave); 0: all at ply 0")
+    ap.add_argument("--burn-in-waves", type=int, default=-1, help="untimed waves before the warm-up steps (default: about two game lengths for the Connect4 configs — 8000 PUCT / "
+                                                                  "2400 Gumbel waves: from the lockstep start the ply mix of 4096 games settles to its stationary state within 16 x 400 waves, "
+                                                                  "tools/ts_probe.py; 0 for Gomoku, whose games last minutes)")
+    ap.add_argument("--stagger", type=int, default=-1, help="1: every slot's first game starts at a random ply of a random legal playout (default for Gomoku only: no burn-in can cover "
+                                                            "a 150-ply game); 0: all games start at ply 0 (default for the Connect4 configs, which burn in instead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-baseline-cores", type=int, default=0, help="worker threads = torch threads of the CPU baseline (0 = the cores this "
@@ -259,25 +263,6 @@ def random_histories(game, n, rng, max_ply):
     return out
 
 
-def selfplay_histories(make_hash_engine, G, rng):
-    """G action histories drawn from the STATIONARY distribution of continuous self-play — the position a slot is in at a random moment — for
-    bench.py's staggered start: G complete games are played by the engine itself with the synthetic hash evaluator (same search, same
-    parameters; a fraction of a second), a game is picked with probability proportional to its length and cut at a uniformly random ply
-    (P(ply = p) ~ #{games longer than p}).  MCTS-played positions, unlike random playouts, have the tactical structure (few immediate wins
-    left standing) that decides how many simulations of a move need the evaluator."""
-    e = make_hash_engine()
-    recs = []
-    for _ in range(4000):
-        e.run_waves(256)
-        recs += e.drain_finished(G)
-        if len(recs) >= G:
-            break
-    e.close()
-    T = np.array([r["T"] for r in recs], np.float64)
-    pick = rng.choice(len(recs), size=G, p=T / T.sum())
-    return [[int(a) for a in recs[i]["actions"][: int(rng.integers(0, recs[i]["T"]))]] for i in pick]
-
-
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -316,6 +301,12 @@ def main():
         net = NETS[game](blocks, seed=0, policy_head="linear" if gumbel else "softmax").eval() if (use_net or not args.no_cpu_baseline) else None
         weights = net.export_engine_weights() if use_net else None
         cache_leg = args.cache_leg if args.cache_leg >= 0 else (0 if config == "gomoku" else 24)
+        # steady state.  The ply mix decides how many simulations of a move need the evaluator (openings ~190 of
+        # 200, late plies a few dozen), i.e. positions/s.  From the lockstep start it oscillates with the period of a game length and is damped
+        # out after ~16 x 400 waves (game lengths spread widely); drawing start positions "from the stationary distribution" by set_position was
+        # tried four ways and each left a LARGER, slower-decaying oscillation (tools/ts_probe.py; gpurun_out r03 ts1 - ts9) — so: burn in.
+        stagger = args.stagger if args.stagger >= 0 else int(game == "Gomoku")
+        burn = args.burn_in_waves if args.burn_in_waves >= 0 else (0 if (game != "Connect4" or emu) else (2400 if gumbel else 8000))
 
         def make_engine(n_sims, cache_log2):
             e = SelfPlayEngine(game, G, n_sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=0 if emu else local,
@@ -325,16 +316,10 @@ def main():
                                eval_cache_log2=cache_log2, lib_path=args.emu_lib or None)
             if use_net:
                 e.load_weights(weights)
-            if args.stagger:
-                # steady state from the first timed wave: every slot starts its first game at a random ply of a
-                # random legal playout — the same positions on every run (seeded by the global slot) — instead of all 4096 at ply 0 in lockstep
-                rs = np.random.default_rng(977 + rank)
-                if game == "Connect4" and not emu:
-                    hs = selfplay_histories(lambda: SelfPlayEngine(game, G, n_sims, max_actions, ef, es, cpuct, alpha, seed=4321, slot_offset=rank * G, device=local,
-                                                                   evaluator=EVAL_HASH, hash_salt=11, ring_capacity=G, games_budget=G,
-                                                                   search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm, c_visit=50.0, c_scale=1.0), G, rs)
-                else:                               # Gomoku: a game is 150 plies x 400 waves — random legal playouts of 0 .. 60 plies instead
-                    hs = random_histories(game, G, rs, {"Gomoku": 60}.get(game, 4))
+            if stagger:
+                # Gomoku: a game is up to 150 plies of 400+ waves — minutes — so no burn-in reaches the stationary ply mix; every slot's first game
+                # starts at a random ply (0 .. 60) of a seeded random legal playout instead, the same positions on every run
+                hs = random_histories(game, G, np.random.default_rng(977 + rank), {"Gomoku": 60}.get(game, 4))
                 for slot, h in enumerate(hs):
                     if h:
                         e.set_position(slot, h)
@@ -355,8 +340,10 @@ def main():
                 return float(tt.item())
             return dt
 
-        def timed_run(e, with_timing):
-            """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; -> (seconds (max over ranks), counter deltas)"""
+        def timed_run(e, with_timing, burn_scale=1.0):
+            """burn-in, W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; -> (seconds (max over ranks), counter deltas)"""
+            for i in range(0, int(burn * burn_scale), 500):
+                e.run_waves(min(500, int(burn * burn_scale) - i)); e.synchronize()
             for i in range(warmup):
                 e.run_waves(args.waves_per_step); e.synchronize()
             barrier(e)
@@ -473,11 +460,9 @@ def main():
                        config=dict(workload=f"{label}, {G} concurrent games/GPU, {sims} sims/move (MCTS.run iteration_limit), "
                                             f"{blocks}-block x128 ResNet bf16, {search} self-play, random-init weights",
                                    games_per_gpu=G, sims_per_move=sims, evaluator=args.evaluator, waves_per_step=args.waves_per_step,
-                                   start=(("every slot's first game starts at a position drawn from the stationary distribution of continuous self-play: complete games played by "
-                                           "the engine with the synthetic hash evaluator, picked in proportion to their length, cut at a uniform ply"
-                                           if (game == "Connect4" and not emu) else "every slot's first game starts at a random ply (0 .. 60) of a seeded random legal playout") +
-                                          " — games out of step from the first timed wave (steady state); later games start at ply 0 as they restart on device")
-                                   if args.stagger else "all games at ply 0",
+                                   start=("every slot's first game starts at a random ply (0 .. 60) of a seeded random legal playout (a Gomoku game lasts minutes: no burn-in reaches "
+                                          "the stationary ply mix)" if stagger else f"all games at ply 0, then {burn} untimed burn-in waves + the warm-up steps: the ply mix of the "
+                                          "games (which decides evaluations per position) has settled to its stationary state before the timed region"),
                                    parallelism=f"games sharded x{world} (rank r owns global slots [r G, (r + 1) G)), counters all-reduced"),
                        detail=dict(positions=positions, positions_per_rank=[int(x) for x in per_rank],
                                    positions_per_rank_min=int(per_rank.min()), positions_per_rank_max=int(per_rank.max()),
@@ -510,7 +495,7 @@ def main():
         if legs and ref_leg and not gumbel:
             sims3 = int(sims * 1.5)
             e3 = make_engine(sims3, args.eval_cache)
-            dt3, d3 = timed_run(e3, False)
+            dt3, d3 = timed_run(e3, False, 1.5)
             t3 = reduce_stats(d3[:5], world)
             e3.close()
             if rank == 0:

@@ -100,6 +100,16 @@ template <class G> GAZ_KERNEL k_set_position(DevParams<G> E, int g, const int32_
     for (int t = 0; t < 2; ++t) { TreeState& ts = E.trees[(size_t)g * 2 + t]; ts.root = -1; ts.n_nodes = 0; ts.root_visits = 0; ts.event = 0; }
 }
 
+// gaz_engine_read_positions: the action history of every slot's game in progress (what gaz_engine_set_position takes)
+template <class G> GAZ_KERNEL k_read_positions(DevParams<G> E, int32_t* n_hist, uint8_t* hist, int stride) {
+    const int g = block_id();
+    if (g >= E.n_games) return;
+    const GameState<G>& gs = E.games[g];
+    const int n = gs.phase == PH_HALT ? 0 : gs.n_hist;
+    for (int i = lane_id(); i < stride; i += WAVE) hist[(size_t)g * stride + i] = i < n ? gs.hist[i] : (uint8_t)0;
+    if (lane_id() == 0) n_hist[g] = n;
+}
+
 template <class G> GAZ_KERNEL k_start_search(DevParams<G> E) {      // PH_IDLE -> build the missing root(s), then MCTS.run
     const int g = block_id();
     if (g >= E.n_games || lane_id() != 0) return;
@@ -274,6 +284,7 @@ struct gaz_engine {
     virtual int read_head_features(int, float*, float*, int32_t*, int32_t*) = 0;
     virtual int set_fused_wave(int) = 0;
     virtual int debug_fused_fault(int) = 0;
+    virtual int read_positions(int32_t*, uint8_t*, int) = 0;
     virtual int repack(int32_t*, int32_t*) = 0;
     virtual int probe_rules(const int32_t*, const int32_t*, int, int, int8_t*, uint8_t*, int32_t*, int8_t*, int32_t*, const float*, float*) = 0;
 };
@@ -910,6 +921,18 @@ template <class G> struct EngineT : gaz_engine {
         HIP_OK(hipGetLastError());
         return 0;
     }
+    uint8_t* dHist = nullptr;
+    int read_positions(int32_t* n_hist, uint8_t* hist, int stride) override {
+        if (!n_hist || !hist || stride < G::MAXT) return fail("read_positions: hist must hold at least max_T actions per slot");
+        if (stride > G::TPAD) stride = G::TPAD;
+        if (!dHist && dalloc(&dHist, (size_t)E.n_games * G::TPAD)) return 1;
+        GAZ_LAUNCH(k_read_positions<G>, E.n_games, WAVE, stream, E, dPhase, dHist, stride);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(n_hist, dPhase, (size_t)E.n_games * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(hist, dHist, (size_t)E.n_games * stride, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
     int start_search() override { GAZ_LAUNCH(k_start_search<G>, E.n_games, WAVE, stream, E); HIP_OK(hipGetLastError()); return 0; }
     int stop_search(int stop) override { E.stop_search = stop != 0; return 0; }
     // tau != 0 and tau <= 5e-3 -> 0 (MCTS.py:116-120,163-168); negative = Self_Play's schedule
@@ -1078,6 +1101,7 @@ int gaz_engine_start_search(gaz_engine* h) { return h->start_search(); }
 int gaz_engine_set_hyperparams(gaz_engine* h, const gaz_search_hyperparams* hp) { return h->set_hyperparams(hp); }
 int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on) { return h->set_fused_wave(on); }
 int gaz_engine_debug_fused_fault(gaz_engine* h, int32_t mod) { return h->debug_fused_fault(mod); }
+int gaz_engine_read_positions(gaz_engine* h, int32_t* n_hist, uint8_t* hist, int32_t stride) { return h->read_positions(n_hist, hist, stride); }
 int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch) { return h->repack(n_active, n_launch); }
 int gaz_engine_read_head_features(gaz_engine* h, int32_t n, float* p, float* v, int32_t* p_row, int32_t* v_row) { return h->read_head_features(n, p, v, p_row, v_row); }
 int gaz_engine_probe_rules(gaz_engine* h, const int32_t* actions, const int32_t* n_actions, int32_t n_positions, int32_t stride, int8_t* board,

@@ -95,6 +95,7 @@ def load_library(lib_path=None):
     L.gaz_engine_probe_rules.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.gaz_engine_set_fused_wave.argtypes = [H, C.c_int32]
     L.gaz_engine_debug_fused_fault.argtypes = [H, C.c_int32]
+    L.gaz_engine_read_positions.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32]
     L.gaz_engine_repack.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_read_head_features.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gaz_engine_dominant_kernel.argtypes = [H, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]
@@ -103,7 +104,7 @@ def load_library(lib_path=None):
     for f in ("create", "load_weights", "reset_games", "run_move", "get_root_stats", "apply_moves", "run_waves", "wave_begin",
               "wave_end", "batch_ptrs", "read_batch", "write_outputs", "evaluate", "record_layout", "drain_finished", "get_stats",
               "synchronize", "timing_reset", "timing_get", "dominant_kernel", "set_position", "set_search_params", "start_search", "stop_search",
-              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave", "debug_fused_fault", "repack"):
+              "set_hyperparams", "probe_rules", "read_head_features", "set_fused_wave", "debug_fused_fault", "read_positions", "repack"):
         getattr(L, "gaz_engine_" + f).restype = C.c_int
     _LIBS[path] = L
     return L
@@ -216,6 +217,13 @@ class SelfPlayEngine:
     def set_position(self, slot, action_indices):
         a = np.ascontiguousarray(action_indices, np.int32)
         self._ck(self.L.gaz_engine_set_position(self.h, int(slot), a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+
+    def read_positions(self):
+        """-> list of action-index histories, one per slot: the game in progress (game.action_history; [] for a halted slot)"""
+        T = int(self.layout.t_pad)
+        n = np.zeros(self.cfg.n_games, np.int32); h = np.zeros((self.cfg.n_games, T), np.uint8)
+        self._ck(self.L.gaz_engine_read_positions(self.h, n.ctypes.data, h.ctypes.data, T))
+        return [h[g, :n[g]].astype(np.int32).tolist() for g in range(self.cfg.n_games)]
 
     def start_search(self):
         self._ck(self.L.gaz_engine_start_search(self.h))

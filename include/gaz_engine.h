@@ -21,6 +21,7 @@
  *   gaz_engine_drain_finished  the per-game arrays play() hands to HDF5        Self_Play.py:159-175
  *   gaz_engine_get_stats       file["game_stats"] u32[6]                       Self_Play.py:181-188
  *   gaz_engine_set_position    MCTS.__init__ attaching to a live game object   MCTS.py:100,132,296-313
+ *   gaz_engine_read_positions  game.action_history of every game in progress      Guide.py:111-133 (the attribute MCTS reads at MCTS.py:297-313)
  *   gaz_engine_set_search_params  run(iteration_limit) / update_hyperparams(tau) MCTS.py:134-168,528
  *   gaz_engine_set_hyperparams    MCTS.update_hyperparams(c_puct_*, dirichlet_*, tau) MCTS.py:134-168;
  *                                 MCTS_Gumbel.update_hyperparams(m, c_visit, c_scale)  MCTS_Gumbel.py:186-210
@@ -219,6 +220,11 @@ int gaz_engine_debug_fused_fault(gaz_engine* h, int32_t mod);
  * gaz_engine_reset_games with a slot list are refused from then on; gaz_engine_reset_games(h, NULL, 0) restarts every slot and makes the
  * launches cover all of them again.  The batch-level calls (read_batch / write_outputs / get_root_stats) keep addressing physical rows. */
 int gaz_engine_repack(gaz_engine* h, int32_t* n_active, int32_t* n_launch);
+
+/* The action history of every slot's game in progress — game.action_history of the reference's Game objects, as action indices; what
+ * gaz_engine_set_position takes.  n_hist int32 [n_games] (0 for a halted slot), hist uint8 [n_games][stride] with stride >= the game's
+ * max_T (gaz_record_layout.max_T).  Synchronises the engine's stream.  bench.py draws its staggered start from it. */
+int gaz_engine_read_positions(gaz_engine* h, int32_t* n_hist, uint8_t* hist, int32_t stride);
 
 /* measurement hooks (bench.py): HIP-event timing of the kernels launched on the engine's stream */
 int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);
