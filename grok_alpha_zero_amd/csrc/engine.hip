@@ -354,7 +354,7 @@ template <class G> struct EngineT : gaz_engine {
         E.explore_first = cfg.num_explore_actions_first; E.explore_second = cfg.num_explore_actions_second;
         E.create_new_root = cfg.create_new_root; E.sync_moves = cfg.sync_moves; E.use_dirichlet = cfg.use_dirichlet;
         int npt = cfg.nodes_per_tree;
-        if (npt <= 0 && gumbel) npt = 2 * (cfg.run_iterations + cfg.gumbel_m) + 3 * G::A + 64;   // fresh tree every move
+        if (npt <= 0 && gumbel) npt = 2 * ((cfg.move_time_limit > 0.0 && 3 * G::A > cfg.run_iterations ? 3 * G::A : cfg.run_iterations) + cfg.gumbel_m) + 3 * G::A + 64;   // fresh tree every move
         if (npt <= 0 && E.compact) {   // per half: kept subtree + one run; generous bound, ERR_ARENA_FULL if a game exceeds it
             const int its = cfg.run_iterations < 3 * G::A ? 3 * G::A : cfg.run_iterations;
             npt = 4 * its + 3 * G::A + 64;
@@ -367,6 +367,9 @@ template <class G> struct EngineT : gaz_engine {
         E.nodes_per_tree = npt;
         E.ring_cap = cfg.ring_capacity; E.single_tree = cfg.single_tree;
         E.tau = norm_tau(cfg.tau); E.no_gumbel_noise = cfg.no_gumbel_noise; E.first_game_seq = cfg.first_game_seq;
+        if (!(cfg.move_time_limit >= 0.0) || cfg.move_time_limit > 1e6) return fail("move_time_limit must be in [0, 1e6] seconds");
+        if (cfg.move_time_limit > 0.0 && cfg.sync_moves) return fail("move_time_limit is for continuous self-play; the per-move API has gaz_engine_stop_search");
+        E.move_time_ticks = cfg.move_time_limit > 0.0 ? (uint64_t)(cfg.move_time_limit * 1e8) + 1 : 0;
         if (cfg.games_budget < 0) return fail("games_budget must be >= 0");
         if (cfg.games_budget > 0 && cfg.sync_moves) return fail("games_budget needs continuous self-play (sync_moves = 0)");
         E.games_budget = cfg.games_budget;

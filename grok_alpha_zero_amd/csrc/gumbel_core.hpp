@@ -21,6 +21,7 @@ namespace gaz {
 
 template <class G> struct GumbelState {          // per game, lives across launches of one MCTS_Gumbel.run
     int32_t m_eff, phase, n_top, cand, stage, sims_left, vpc, cur_iter, pend_counts;
+    int32_t iter_limit, pad_;  // this move's iteration_limit: run_iterations, or 3 x legal moves under a time limit (DevParams::move_time_ticks)
     float top_logits[G::APAD];
     float top_mean[G::APAD];
     uint8_t top_ids[G::APAD];
@@ -306,8 +307,9 @@ template <class G> GAZ_DEV bool g_halving(const DevParams<G>& E, GumbelState<G>&
     double lg2;                                              // np.log2(m): exact for powers of two
     if ((m & (m - 1)) == 0) { lg2 = 0.0; for (int mm = m; mm > 1; mm >>= 1) lg2 += 1.0; }
     else lg2 = det::dlog((double)m) / 0.6931471805599453;
-    int vpc = m > 1 ? (int)((double)E.run_iterations / (lg2 * halved)) : E.run_iterations; if (vpc < 1) vpc = 1;
-    if (take == 2 || take == 3) { vpc = (E.run_iterations - gu.cur_iter) / take; if (vpc < 1) vpc = 1; }
+    const int iters = tuni<G>(gu.iter_limit);
+    int vpc = m > 1 ? (int)((double)iters / (lg2 * halved)) : iters; if (vpc < 1) vpc = 1;
+    if (take == 2 || take == 3) { vpc = (iters - gu.cur_iter) / take; if (vpc < 1) vpc = 1; }
     wave_sync();
     if (tlane<G>() == 0) { gu.n_top = take; gu.vpc = vpc; gu.cand = 0; gu.stage = 0; }
     wave_sync();
@@ -532,6 +534,7 @@ template <class G, class Fin> GAZ_DEV void g_game_step_body(const DevParams<G>& 
             if (tlane<G>() == 0) {
                 if (!E.no_gumbel_noise) ts.event += 1;
                 gu.m_eff = E.gumbel_m < len_legal ? E.gumbel_m : len_legal; gu.phase = 0; gu.n_top = n; gu.cur_iter = 0;
+                gu.iter_limit = E.move_time_ticks ? 3 * len_legal : E.run_iterations;
                 gu.cand = 0; gu.stage = 0; gu.sims_left = 0; gu.pend_counts = 0;
             }
             wave_sync();

@@ -41,6 +41,10 @@ template <class G> struct DevParams {
     double c_visit, c_scale;   // Gumbel (MCTS_Gumbel.py:160-161)
     int32_t gumbel_m, node_bytes, compact;
     int32_t stop_search;       // host clock expired (MCTS.run(time_limit), MCTS.py:560-563): finish the move now
+    // train_config["MCTS_time_limit"] (Self_Play.py:35,100-112), 0 = none.  PUCT: a move ends when its own wall clock (100 MHz ticks since
+    // MOVE_BEGIN) passes the limit or its iterations are used up, whichever comes first (MCTS.py:559-560).  Gumbel: any limit makes every move run
+    // 3 x its legal moves iterations instead of run_iterations, as the reference does ("Time limit isn't allowed for gumbel", MCTS_Gumbel.py:576-578)
+    uint64_t move_time_ticks;
     int32_t fast_find_win;     // MCTS(fast_find_win=True): keep only the first winning move of a position (MCTS.py:282-283)
     int32_t g_stablemax;       // Gumbel: activation_fn = "stablemax" in deterministic_selection (Self_Play.py:69)
     int32_t single_tree;       // 1: one tree searches for both players (MCTS used on its own, e.g. Connect4/play.py, Game_Tester.py:480-513)
@@ -917,11 +921,15 @@ template <class G, class Fin> GAZ_DEV void game_step_body(const DevParams<G>& E,
                 int lim = E.run_iterations;
                 if (len_legal == 1) lim = 1; else if (lim < len_legal) lim = len_legal * 3;
                 gs.iter_limit = lim; gs.sims_done = 0; gs.fully_visited = 0; gs.move_evals = 0;
+                if (E.move_time_ticks) gs.move_t0 = (uint64_t)wall_clock64();
                 gs.phase = PH_SIMS;
             }
             wave_sync();
         } else if (phase == PH_SIMS) {                                 // MCTS.run loop body (MCTS.py:560-587)
-            if (tuni<G>(gs.sims_done) >= tuni<G>(gs.iter_limit) || (E.stop_search && tuni<G>(gs.sims_done) > 0)) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); return false; }
+            // (only once every root child has been visited: stopping earlier, the reference divides by zero visits at MCTS.py:594-595 under its
+            // np.seterr(all="raise") — a limit that short is an error there, a floor of one visit per root child here)
+            const bool out_of_time = E.move_time_ticks && tuni<G>(gs.fully_visited) && tuni<G>((int)((uint64_t)wall_clock64() - gs.move_t0 > E.move_time_ticks));
+            if (tuni<G>(gs.sims_done) >= tuni<G>(gs.iter_limit) || ((E.stop_search || out_of_time) && tuni<G>(gs.sims_done) > 0)) { if (tlane<G>() == 0) gs.phase = PH_MOVE_END; wave_sync(); return false; }
             const int t = tuni<G>(gs.runner);
             TreeState& ts = trees[t];
             NodeRef<G> r = node_at(E, g, t, ts.root);

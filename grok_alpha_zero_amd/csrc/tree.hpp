@@ -91,6 +91,7 @@ template <class G> struct GameState {
     uint32_t move_evals;       // evaluator calls during the current run()
     uint64_t n_evals, n_sims, n_plies;  // lifetime counters of this slot (n_plies = positions played)
     uint64_t n_hits;           // evaluations answered by the on-device evaluation cache (included in n_evals)
+    uint64_t move_t0;          // wall clock at MOVE_BEGIN (DevParams::move_time_ticks)
     uint32_t slot_id;          // the game's GLOBAL slot (slot_offset + the physical slot it started in): RNG streams and the record
     uint32_t pad_;             // header carry this, not the physical index, so gaz_engine_repack may move a running game
 };

@@ -138,7 +138,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     const int HW = a.H * a.W;
     // image row -> (cell of its board, global row); false for padding rows and rows beyond the batch.  Natural layout: image row q <-> global row
     // m0 + q; SKIPSET variants: board b of the tile starts at image row byte b of boffp (TrunkArgs::boff)
-    auto locate = [&](const int row, int& cell, long& grow) -> bool {
+    auto locate = [&](const int row, int& cell, long& grow, const unsigned bo = 0xFFFFFFFFu) -> bool {      // bo: see the heads phase
+        const unsigned boffq = bo == 0xFFFFFFFFu ? boffp : bo;
         if constexpr (SKIPSET == 0) {
             cell = row % HW; grow = m0 + row;
             return row < tile_rows && grow < a.M;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
             bool ok = false; cell = 0; grow = 0;
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const int o = (int)((boffp >> (8 * b)) & 0xFFu);
+                const int o = (int)((boffq >> (8 * b)) & 0xFFu);
                 if (b * HW < tile_rows && row >= o && row < o + HW) {
                     cell = row - o;
                     // completion queue: board b of the tile is the game its queue entry names (Xt[1 + b], written before the barrier below; -1 = no entry)
@@ -379,14 +380,17 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     for (int g = 0; g < KS32; ++g)
 #pragma unroll
         for (int ct = 0; ct < NCH; ++ct) wfr[g][ct] = ldw(0, g, ct);
-    int crow[NC]; unsigned cmask[NC];
+    // crow (image row, < 256) and the nine tap-validity bits share one register per MFMA tile: they are live across the whole block loop, and the
+    // edge-tile variants have no register to spare (round 3: packing them is what keeps the queue / board-offset geometry from spilling)
+    unsigned cgeo[NC];
+    auto crow_of = [&](int t) -> int { return (int)(cgeo[t] & 0xFFu); };
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
         const int mrow = wm * TM * 32 + t * 16 + l15;
-        crow[t] = perm ? (int)perm[mrow] : mrow;
+        const int crow_t = perm ? (int)perm[mrow] : mrow;
         unsigned mm = 0;
         int cell; long grow_;
-        if (locate(crow[t], cell, grow_)) {
+        if (locate(crow_t, cell, grow_)) {
             const int y = cell / a.W, x = cell % a.W;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
@@ -394,10 +398,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 mm |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << q;
             }
         }
-        cmask[t] = mm;
+        cgeo[t] = (unsigned)crow_t | (mm << 8);
     }
     auto off16 = [&](int ct, int t) -> int {        // this lane's 8-byte group (channels 16 ct + 4 lq ..+3 of the wave's slab) of cell crow[t]
-        const int row = crow[t], cslot = wn * TN * 4 + ct * 2 + (lq >> 1);
+        const int row = crow_of(t), cslot = wn * TN * 4 + ct * 2 + (lq >> 1);
         return row * 256 + (swz_slot<true>(cslot, row) << 4) + (lq & 1) * 8;
     };
     f32x4 acc16[NCH][NC];
@@ -412,8 +416,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         const int ty = tap / 3, off = (ty - 1) * a.W + (tap - ty * 3 - 1);
 #pragma unroll
         for (int t = 0; t < NC; ++t) {
-            const bool ok = (cmask[t] >> tap) & 1u;
-            const int ar = ok ? crow[t] + off : ZROW + ((crow[t] + off) & 15);
+            const bool ok = (cgeo[t] >> (8 + tap)) & 1u;
+            const int ar = ok ? crow_of(t) + off : ZROW + ((crow_of(t) + off) & 15);
             o[t] = ((int)ldsb | zz) + ar * 256 + (swz_slot<true>(lq, ar) << 4);   // k-step ks: ^ (ks << 5), see below
         }
     };
@@ -889,8 +893,12 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         for (int g = 0; g < HRING; ++g) hfr[g] = ldh(g / KS, g % KS);
         const int hrow = waveh * 32 + l31h;         // cell tile `wave` of the workgroup
         unsigned hmask = 0;
+        // (an opaque copy of the packed board offsets: decoded from the SAME value as before the block loop, the three offsets stay live across it —
+        // in scalar registers the edge-tile variants do not have: they were spilled to scratch memory, 40 MB of HBM traffic per launch)
+        unsigned boh = boffp & 0x00FFFFFFu;
+        asm volatile("" : "+s"(boh));
         int hcell; long hgr;
-        const bool hok = locate(hrow, hcell, hgr);
+        const bool hok = locate(hrow, hcell, hgr, boh);
         if (hok) {
             const int cell = hcell, y = cell / a.W, x = cell % a.W;
 #pragma unroll

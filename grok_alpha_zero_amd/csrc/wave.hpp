@@ -40,6 +40,8 @@ template <class T> inline T atomic_add(T* p, T v) { T o = *p; *p = o + v; return
 template <class T> inline T atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomic_exch(T* p, T v) { T o = *p; *p = v; return o; }
 }  // namespace gaz
+#include <time.h>
+inline long long wall_clock64() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (long long)t.tv_sec * 100000000ll + t.tv_nsec / 10; }   // 100 MHz, as the device's
 #else
 #include <hip/hip_runtime.h>
 #define GAZ_DEV __device__ __forceinline__

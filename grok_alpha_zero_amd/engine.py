@@ -33,7 +33,7 @@ class EngineConfig(C.Structure):       # gaz_engine_config — tests/test_abi.py
                 ("gumbel_m", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double), ("compact_trees", C.c_int32),
                 ("single_tree", C.c_int32), ("n_opening", C.c_int32), ("opening_actions", C.c_int32 * 8),
                 ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32), ("fast_find_win", C.c_int32),
-                ("no_gumbel_noise", C.c_int32), ("first_game_seq", C.c_uint32), ("games_budget", C.c_int64), ("tau", C.c_double)]
+                ("no_gumbel_noise", C.c_int32), ("first_game_seq", C.c_uint32), ("games_budget", C.c_int64), ("tau", C.c_double), ("move_time_limit", C.c_double)]
 
 
 class SearchHyperparams(C.Structure):  # gaz_search_hyperparams
@@ -124,7 +124,7 @@ class SelfPlayEngine:
                  evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
                  policy_is_logits=False, max_tree_sims_per_wave=0, gumbel_m=0, c_visit=50.0, c_scale=1.0,
                  compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, fast_find_win=False,
-                 use_gumbel_noise=True, first_game_seq=0, games_budget=0, tau=-1.0, lib_path=None):
+                 use_gumbel_noise=True, first_game_seq=0, games_budget=0, tau=-1.0, move_time_limit=0.0, lib_path=None):
         self.L = load_library(lib_path)
         self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
         self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
@@ -142,7 +142,7 @@ class SelfPlayEngine:
                                 max_tree_sims_per_wave=max_tree_sims_per_wave, eval_cache_log2=int(eval_cache_log2),
                                 gumbel_stablemax=int(gumbel_stablemax), fast_find_win=int(fast_find_win),
                                 no_gumbel_noise=int(not use_gumbel_noise), first_game_seq=int(first_game_seq), games_budget=int(games_budget),
-                                tau=float(tau))
+                                tau=float(tau), move_time_limit=float(move_time_limit or 0.0))
         for i, (a, w) in enumerate(opening_actions or []):       # [(action index, weight)] — train_config["opening_actions"]
             self.cfg.opening_actions[i] = int(a); self.cfg.opening_weights[i] = float(w); self.cfg.n_opening = i + 1
         self.h = C.c_void_p()

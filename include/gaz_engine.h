@@ -104,6 +104,11 @@ typedef struct {
     double tau;                   /* MCTS(tau=...) (MCTS.py:116-120,602-610): < 0 = Self_Play's schedule (tau 1 for the first
                                      num_explore_actions plies of each player, then 0); 0 = most visited move; > 0 = sample with
                                      weights N^(1/tau).  gaz_engine_set_hyperparams changes it between runs */
+    double move_time_limit;       /* train_config["MCTS_time_limit"] in seconds (Self_Play.py:35,100-112), 0 = none.  PUCT: every game's move ends when its
+                                     own wall clock since the move began passes the limit or run_iterations are used up, whichever comes first — at
+                                     least one simulation (MCTS.py:559-560); results then depend on timing, as in the reference.  Gumbel: any
+                                     limit makes every move run 3 x its legal moves iterations ("Time limit isn't allowed for gumbel",
+                                     MCTS_Gumbel.py:576-578).  Continuous self-play only */
 } gaz_engine_config;
 
 /* MCTS.update_hyperparams(**kwargs) (MCTS.py:134-168) / MCTS_Gumbel.update_hyperparams (MCTS_Gumbel.py:186-210): values take

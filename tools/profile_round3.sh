@@ -11,7 +11,7 @@ echo "== bench (driver command)"; timeout -k 10 500 python bench.py --gpus 1 --s
 for k in 8 40; do echo "== bench --steps $k"; timeout -k 10 300 python bench.py --steps $k --warmup 5 $short > $out/bench_steps$k.json 2> $out/bench_steps$k.err || exit 1; done
 echo "== rocprofv3 --kernel-trace --stats (headline + legs, 3 steps)"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --cache-leg 0 --ref-convention-leg 0 > $out/stats.log 2>&1 || exit 1
-pm="--steps 1 --warmup 0 --waves-per-step 40 $short"
+pm="--steps 1 --warmup 0 --waves-per-step 40 --burn-in-waves 400 $short"
 for c in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "l SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   set -- $c; d=$1; shift
   echo "== rocprofv3 --pmc $*"
