@@ -382,8 +382,15 @@ template <class G> struct EngineT : gaz_engine {
         // measured: 32 -> 4 cuts the kernel tail 0.167 -> 0.067 ms; with the evaluation cache a hit is such a simulation too and 8 pays
         // (small boards; a Gomoku simulation is ten times as long and 8 only stretches the launch)
         // (round 2) with the fused tree + trunk launch the tail of the tree step hides behind the trunk: 12 pays there (69.6 k vs 67.9 k)
-        const bool fusable = G::ID == GAME_C4 && cfg.search == GAZ_SEARCH_PUCT && cfg.evaluator == GAZ_EVAL_RESNET;
-        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave : ((cfg.eval_cache_log2 > 0 && G::A <= 64) ? (fusable ? 12 : 8) : 4);
+        // (round 3) with the completion queue and games that yield inside the phase loop, the tree step's tail no longer holds the trunk back, so more
+        // evaluation-free simulations per launch only mean fewer rows without a request: Connect4 PUCT 4: 57.5 k, 8: 59.1 - 60.1 k, 12: 58.7 k;
+        // Gumbel 4: 317 k, 8: 331 k, 16: 337 k; Gomoku 4: 2096, 16: 2177, 32: 2192 positions/s (tools/sweep_mts.sh, one box each)
+        const bool resnet = cfg.evaluator == GAZ_EVAL_RESNET;
+        const bool fusable = G::ID == GAME_C4 && cfg.search == GAZ_SEARCH_PUCT && resnet;
+        const int fused_default = !resnet ? 0 : (G::ID == GAME_C4 ? (gumbel ? (cfg.eval_cache_log2 > 0 ? 0 : 16) : (cfg.eval_cache_log2 > 0 ? 12 : 8))
+                                                                  : (G::ID == GAME_GMK && !gumbel && cfg.eval_cache_log2 == 0 ? 32 : 0));
+        E.max_tree_sims = cfg.max_tree_sims_per_wave > 0 ? cfg.max_tree_sims_per_wave
+                        : (fused_default ? fused_default : ((cfg.eval_cache_log2 > 0 && G::A <= 64) ? (fusable ? 12 : 8) : 4));
         E.c_init = cfg.c_puct_init; E.c_base = cfg.c_puct_base;
         E.alpha = (double)(float)cfg.dirichlet_alpha;     // alpha * np.ones_like(float32 policy) is float32 (MCTS.py:244-245)
         E.eps = cfg.dirichlet_epsilon; E.one_minus_eps = (float)(1.0 - cfg.dirichlet_epsilon);

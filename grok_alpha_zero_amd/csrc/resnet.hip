@@ -318,12 +318,17 @@ __global__ __launch_bounds__(128) void k_dense1(const float* feat, const float* 
 // ---- heads: the same Dense(F -> 128) + folded BN + ReLU for BOTH heads on the matrix cores, exact fp32
 // (v_mfma_f32_32x32x2_f32): block = 32 positions x 128 outputs, 4 waves x 32 columns; blockIdx.y = head.
 struct Dense1Args { const float* feat[2]; const float* w[2]; const float* scale[2]; const float* shift[2]; float* out[2]; int B, F; };
-__global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
-    extern __shared__ float fl[];                  // [32][FP], FP = F rounded up to 16, + 1 (zero-padded columns)
+// Round 3: split-K inside the workgroup.  The kernel is a chain of L2 round trips (168 weight loads per lane with five groups in flight; 5.6 us of
+// MFMA in 16.7 us at one wave per SIMD), so eight waves take half the k-groups each — waves 0-3 the first half, waves 4-7 the second — and the
+// two partial sums meet in LDS: out = relu((first + second) * s + t).  One summation order whatever the batch (rows stay batch-independent).
+constexpr int D1_THREADS = 512;
+__global__ __launch_bounds__(D1_THREADS) void k_dense1_mfma(Dense1Args a) {
+    extern __shared__ float fl[];                  // [32][FP], FP = F rounded up to 16, + 1 (zero-padded columns); then [4][16][64] partial sums
     constexpr int G = 8, D = 6;                    // 16 k per group, six-deep register ring of weight groups
     const int head = blockIdx.y, b0 = blockIdx.x * 32, F = a.F, NG = (F + 2 * G - 1) / (2 * G), FP = NG * 2 * G + 1;
     const float* feat = a.feat[head]; const float* w = a.w[head];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, n = wave * 32 + l31;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5, wq = wave & 3, half = wave >> 2, n = wq * 32 + l31;
+    const int NGH = (NG + 1) / 2, gA = half * NGH, gB = half ? NG : NGH;          // this wave's k-groups [gA, gB)
     // A[i = l31][k + lhi], B[k + lhi][j = l31].  The weights come from L2 (~1 us away under load): the next five groups are in
     // flight while a group multiplies, and the first five are requested BEFORE the features are staged (round 2: the kernel is a chain
     // of round trips with one wave per SIMD, nothing else hides them).  Loads past the last row are clamped (their A columns are zero).
@@ -333,38 +338,38 @@ __global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
         for (int j = 0; j < G; ++j) { const int k = min(g * 2 * G + 2 * j + lhi, F - 1); dst[j] = w[(size_t)k * 128 + n]; }
     };
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) ldg(d, bq[d]);
-    // features -> LDS: one wave per position row, coalesced; loads are unconditional (clamped).  ALL of a wave's loads (8 rows x 6) are
+    for (int d = 0; d < D - 1; ++d) ldg(gA + d, bq[d]);
+    // features -> LDS: one wave per position row, coalesced; loads are unconditional (clamped).  ALL of a wave's loads (4 rows x 6) are
     // issued before its first LDS store: one round trip for the staging instead of one per row.
     {
-        float v[8][6];
+        float v[4][6];
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) {
-            const int p = wave + 4 * pi;
+        for (int pi = 0; pi < 4; ++pi) {
+            const int p = wave + 8 * pi;
             const size_t rb = (size_t)min(b0 + p, a.B - 1) * F;
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[pi][c] = feat[rb + min(lane + 64 * c, F - 1)];
         }
 #pragma unroll
-        for (int pi = 0; pi < 8; ++pi) {
-            const int p = wave + 4 * pi;
+        for (int pi = 0; pi < 4; ++pi) {
+            const int p = wave + 8 * pi;
             const bool rok = b0 + p < a.B;
 #pragma unroll
             for (int c = 0; c < 6; ++c) { const int k = lane + 64 * c; if (k < FP) fl[p * FP + k] = (rok && k < F) ? v[pi][c] : 0.0f; }
         }
-        for (int p = wave; p < 32; p += 4)           // F > 384 (not the Connect4 net): the rest of the row, the old way
+        for (int p = wave; p < 32; p += 8)           // F > 384 (not the Connect4 net): the rest of the row, the old way
             for (int k = lane + 64 * 6; k < FP; k += 64) fl[p * FP + k] = (b0 + p < a.B && k < F) ? feat[(size_t)min(b0 + p, a.B - 1) * F + k] : 0.0f;
     }
     __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int g0 = 0; g0 < NG; g0 += D) {
+    for (int g0 = gA; g0 < gB; g0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int g = g0 + d;
             ldg(g + D - 1, bq[(d + D - 1) % D]);
-            if (g < NG) {                           // wave-uniform
+            if (g < gB) {                           // wave-uniform
                 float av[G];
 #pragma unroll
                 for (int j = 0; j < G; ++j) av[j] = fl[l31 * FP + g * 2 * G + 2 * j + lhi];
@@ -373,11 +378,18 @@ __global__ __launch_bounds__(256) void k_dense1_mfma(Dense1Args a) {
             }
         }
     }
+    float* part = fl + 32 * FP;                    // [wq][r][lane]: the second half's sums
+    if (half) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(wq * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (half) return;
     const float s = a.scale[head][n], t = a.shift[head][n];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (b0 + row < a.B) a.out[head][(size_t)(b0 + row) * 128 + n] = fmaxf(acc[r] * s + t, 0.0f);
+        if (b0 + row < a.B) a.out[head][(size_t)(b0 + row) * 128 + n] = fmaxf((acc[r] + part[(wq * 16 + r) * 64 + lane]) * s + t, 0.0f);
     }
 }
 
@@ -729,7 +741,7 @@ struct ResNetEvaluator : Evaluator {
         Dense1Args d; d.B = n; d.F = F;
         d.feat[0] = pfeat; d.w[0] = f32["p.d1.w"]; d.scale[0] = f32["p.d1.scale"]; d.shift[0] = f32["p.d1.shift"]; d.out[0] = pd1;
         d.feat[1] = vfeat; d.w[1] = f32["v.d1.w"]; d.scale[1] = f32["v.d1.scale"]; d.shift[1] = f32["v.d1.shift"]; d.out[1] = vd1;
-        hipLaunchKernelGGL(k_dense1_mfma, dim3((n + 31) / 32, 2), dim3(256), (size_t)32 * ((F + 15) / 16 * 16 + 1) * 4, s, d);
+        hipLaunchKernelGGL(k_dense1_mfma, dim3((n + 31) / 32, 2), dim3(D1_THREADS), (size_t)32 * ((F + 15) / 16 * 16 + 1) * 4 + 4 * 16 * 64 * 4, s, d);
         TailArgs t; t.p_d1 = pd1; t.v_d1 = vd1; t.p_w2 = f32["p.d2.w"]; t.p_b2 = f32["p.d2.bias"]; t.p_w3 = f32["p.d3.w"];
         t.p_b3 = f32["p.d3.bias"]; t.v_w2 = f32["v.d2.w"]; t.v_b2 = f32["v.d2.bias"]; t.v_w3 = f32["v.d3.w"]; t.v_b3 = f32["v.d3.bias"];
         t.policy = policy; t.value = value; t.B = n; t.A = A; t.logits = logits;

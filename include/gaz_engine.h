@@ -83,7 +83,7 @@ typedef struct {
     int32_t n_opening;            /* train_config["opening_actions"] (Self_Play.py:130-140): up to 8 [action, weight] pairs */
     int32_t opening_actions[8];
     double opening_weights[8];
-    int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = 4);
+    int32_t max_tree_sims_per_wave; /* evaluation-free simulations a game may run per launch before it yields (0 = the configuration's measured default: 4 .. 32);
                                        scheduling only — results do not depend on it */
     int32_t eval_cache_log2;      /* on-device evaluation cache with 2^n entries, keyed by the encoded leaf state (replaces
                                      Session_Cache.Cache_Wrapper, Session_Cache.py:4-26 / Self_Play.py:234-236); 0 = off.
