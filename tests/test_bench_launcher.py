@@ -49,6 +49,8 @@ def test_gpus_2_launches_two_ranks_and_reports_the_aggregate(emu_lib):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 2 and r["warmup"] == 1
     per = r["detail"]["positions_per_rank"]
+    # round 3: the line diagnoses a multi-GPU run by itself — spread of the per-rank work and the wall time of the one collective
+    assert r["detail"]["positions_per_rank_min"] == min(per) and r["detail"]["positions_per_rank_max"] == max(per) and r["detail"]["counters_allreduce_ms"] >= 0.0
     assert len(per) == 2 and all(x > 0 for x in per) and sum(per) == r["detail"]["positions"]
     assert abs(r["value"] - r["detail"]["positions"] / (r["ms_per_step"] * r["steps"] / 1e3)) < 1e-6 * r["value"]
     assert "x2" in r["config"]["parallelism"] and "NOT A MEASUREMENT" in r["data"]

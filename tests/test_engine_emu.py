@@ -276,3 +276,38 @@ def test_emu_skipped_evaluations_are_requested_again(emu_lib, oracle, search, ca
         assert r["T"] == o["T"], r["slot"]
         for k in ("actions", "root_N", "root_W", "policies", "values"):
             np.testing.assert_array_equal(r[k], o[k], err_msg=f"slot {r['slot']} {k}")
+
+
+def test_emu_read_positions_is_the_counterpart_of_set_position(emu_lib):
+    """gaz_engine_read_positions (round 3): every game's action_history (Guide.py:111-133) as action indices — what gaz_engine_set_position takes.
+    A second engine put at those positions continues from exactly them."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine
+    a = SelfPlayEngine("Connect4", 6, 16, 42, 8, 7, 2.5, 0.5, seed=3, hash_salt=1, lib_path=emu_lib)
+    a.run_waves(150)
+    hs = a.read_positions()
+    assert len(hs) == 6 and any(len(h) > 2 for h in hs) and all(0 <= x < 7 for h in hs for x in h)
+    b = SelfPlayEngine("Connect4", 6, 16, 42, 8, 7, 2.5, 0.5, seed=3, hash_salt=1, lib_path=emu_lib)
+    for g, h in enumerate(hs):
+        if h:
+            b.set_position(g, h)
+    b.run_waves(1)
+    back = b.read_positions()
+    assert all(back[g][:len(hs[g])] == hs[g] for g in range(6))
+    a.close(); b.close()
+
+
+def test_bench_random_histories_are_legal_and_unfinished():
+    """bench.py's staggered start for Gomoku: random legal playouts that have not ended."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from grok_alpha_zero_amd.games import GAMES
+    for game, span in (("Gomoku", 30), ("Connect4", 20)):
+        hs = bench.random_histories(game, 25, np.random.default_rng(5), span)
+        assert len(hs) == 25 and max(len(h) for h in hs) <= span
+        for h in hs:
+            g = GAMES[game]()
+            for a in h:
+                assert g.check_win() == -2 if g.action_history else True
+                g.do_action(GAMES[game].index_to_action(int(a)))
+            assert not h or g.check_win() == -2
