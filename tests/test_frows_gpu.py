@@ -137,3 +137,34 @@ def test_evaluation_cache_on_matches_the_oracle(oracle):
         for k in ("actions", "root_N", "root_visits", "root_W", "root_P", "policies", "values", "q", "evals"):
             np.testing.assert_array_equal(r[k], o[k], err_msg=f"{k} slot {slot}")
     probe.close()
+
+
+def test_keras_weight_file_drives_the_hip_evaluator(tmp_path):
+    """SURVEY 8f rank 2 on the GPU ("no -m gpu test"): a Keras-3-style `model.weights.h5` (Connect4/main.py:119,135 writes one per
+    generation) -> keras_weights.load_keras_weights -> export_engine_weights -> gaz_engine_load_weights -> the MFMA evaluator, against the fp32
+    network the file was written from.  Parity with a REAL Keras file stays unpinned (no TensorFlow here, no weight file in the reference): this
+    pins the importer's layout rules end to end through the HIP path — a transposed kernel or a BN vector in the wrong slot moves the outputs
+    far beyond the bf16 tolerance."""
+    from grok_alpha_zero_amd import h5io
+    if not h5io.available():
+        pytest.skip("libhdf5 not available")
+    import torch
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.keras_weights import load_keras_weights, save_keras_style
+    from grok_alpha_zero_amd.net import Connect4Net
+    src = Connect4Net(6, seed=21).eval().randomize_bn(3)
+    path = str(tmp_path / "model.weights.h5")
+    save_keras_style(src, path)
+    net = load_keras_weights(path, Connect4Net(6, seed=99)).eval()
+    eng = SelfPlayEngine("Connect4", 256, 200, 42, 8, 7, 2.5, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=6, ring_capacity=0)
+    eng.load_weights(net.export_engine_weights())
+    x = np.random.default_rng(8).integers(-1, 2, size=(200, 6, 7, 4)).astype(np.int8)
+    pol, val, _ = eng.evaluate(x)
+    eng.close()
+    with torch.no_grad():
+        p_ref, v_ref = src(torch.from_numpy(x))
+    assert np.abs(pol - p_ref.numpy()).max() <= 6e-2 and np.abs(val - v_ref.numpy().reshape(-1)).max() <= 0.1
+    scr = Connect4Net(6, seed=99).eval()                                     # the importer's target before loading: must NOT match
+    with torch.no_grad():
+        p_bad, _ = scr(torch.from_numpy(x))
+    assert np.abs(p_bad.numpy() - p_ref.numpy()).max() > 6e-2
