@@ -1265,6 +1265,7 @@ typedef TeamGame<GAME_C4> GP4;
 template <class GP, class LOCAL, bool GUMBEL, int THREADS = TR_THREADS, size_t LDS_BYTES = trunk_lds_bytes(96)>
 __device__ GAZ_TREE_ROLE_ATTR void tree_role(const DevParams<GP>& E, int g0, int g1, uint4* lds) {
     constexpr int PER = WAVE / GP::TEAM, NT = (THREADS / WAVE) * PER;
+    // (measured and dropped: s_setprio 3 for the tree waves — no change, 60.8 k vs 60.8 k / 339.7 k vs 339.6 k: they wait on memory round trips, not on issue slots)
     Scratch<GP>* S = reinterpret_cast<Scratch<GP>*>(lds);
     LOCAL* L = reinterpret_cast<LOCAL*>(S + NT);
     uint32_t* rank = reinterpret_cast<uint32_t*>(L + NT);           // completion queue: how many games of this block have finished (DevParams::done_queue)
