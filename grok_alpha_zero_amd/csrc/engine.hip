@@ -1057,6 +1057,182 @@ template <class G> struct EngineT : gaz_engine {
     }
 };
 
+// ------------------------------------------------------------------------------------------ game groups
+// gaz_engine_config::game_groups: the games of ONE engine handle as K independent engines (groups of consecutive slots), each with its own
+// stream, batch and fused tree + trunk launch, stepped alternately by run_waves.  Nothing of a game depends on how games are grouped — RNG streams
+// and records are keyed by the GLOBAL slot (slot_offset + slot), rows of an evaluator batch are independent bit for bit — so every game is the one
+// a single engine plays (tests: records equal by (slot, game_seq)); only the order in which finished games reach the ring differs.
+// Why: a wave of one engine is tree step -> trunk -> heads in sequence; in the one-launch form the trunk workgroups still wait ~60 us for their
+// first boards, the last round of tiles leaves slots idle and the heads (Dense-1 + tail, ~27 us) run on a nearly empty chip.  With TWO launches
+// of half the games in flight, the other group's trunk tiles fill all of that: Connect4 headline config, steady state, one box: 7.84 M -> 8.60 M
+// evaluations/s with 2048 | 2048 (2560 | 1536: 8.14 M; 3072 | 1024: 7.19 M; three groups 7.73 M; four 7.1 M; Gumbel 8192 -> 2 x 4096: -1 %;
+// Gomoku 2 x 1024: -10 %) — so auto = 2 only for Connect4 PUCT + ResNet from 3072 games.
+static gaz_engine* make_single_engine(const gaz_engine_config& cfg, std::string* err) {
+    gaz_engine* h = nullptr;
+    switch (cfg.game) {
+        case GAZ_GAME_TICTACTOE: h = new EngineT<Game<GAME_TTT>>(); break;
+        case GAZ_GAME_CONNECT4: h = new EngineT<Game<GAME_C4>>(); break;
+        case GAZ_GAME_GOMOKU: h = new EngineT<Game<GAME_GMK>>(); break;
+        default: *err = "unknown game id"; return nullptr;
+    }
+    h->cfg = cfg; h->cfg.game_groups = 1;
+    if (h->init()) { *err = h->err; delete h; return nullptr; }
+    return h;
+}
+
+struct GroupEngine : gaz_engine {
+    std::vector<gaz_engine*> kid;
+    std::vector<int> first;                          // first[c] = first slot of group c, first[K] = n_games
+    gaz_record_layout lay{};
+    int drain_from = 0;
+    ~GroupEngine() override { for (gaz_engine* k : kid) delete k; }
+    int K() const { return (int)kid.size(); }
+    int size_of(int c) const { return first[c + 1] - first[c]; }
+    int up(gaz_engine* k, int rc) { if (rc) err = k->err; return rc; }
+    template <class F> int each(F f) { for (int c = 0; c < K(); ++c) if (up(kid[c], f(kid[c], c))) return 1; return 0; }
+    int group_of(int slot) const { int c = 0; while (c + 1 < K() && slot >= first[c + 1]) ++c; return c; }
+
+    int init() override {
+        const int n = cfg.n_games, k = cfg.game_groups;
+        if (k < 2 || k > n) return fail("game_groups must be in [1, n_games]");
+        if (cfg.sync_moves || cfg.evaluator == GAZ_EVAL_EXTERNAL) return fail("game_groups > 1 needs continuous self-play (sync_moves = 0) with a built-in evaluator");
+        if (cfg.games_budget > 0 && cfg.games_budget < n) return fail("game_groups > 1 with a games_budget below n_games: a group could be left without a game (use game_groups = 1)");
+        first.assign(1, 0);
+        for (int c = 0; c < k; ++c) first.push_back(first.back() + n / k + (c < n % k ? 1 : 0));
+        for (int c = 0; c < k; ++c) {
+            gaz_engine_config cc = cfg;
+            cc.n_games = size_of(c); cc.slot_offset = cfg.slot_offset + (uint32_t)first[c];
+            if (cfg.ring_capacity > 0) cc.ring_capacity = (int32_t)(((int64_t)cfg.ring_capacity * cc.n_games + n - 1) / n);
+            if (cfg.games_budget > 0) {
+                // one engine: slot g plays its k-th game iff k n + g < budget, i.e. floor(budget / n) games and one more in the first budget % n slots;
+                // the group's own rule (k n_c + g_c < budget_c) gives exactly those games with this budget
+                const int64_t whole = cfg.games_budget / n, extra = cfg.games_budget % n - first[c];
+                cc.games_budget = whole * cc.n_games + (extra < 0 ? 0 : (extra > cc.n_games ? cc.n_games : extra));
+            }
+            std::string e;
+            gaz_engine* h = make_single_engine(cc, &e);
+            if (!h) return fail("game group " + std::to_string(c) + ": " + e);
+            kid.push_back(h);
+        }
+        return kid[0]->record_layout(&lay);
+    }
+    int load_weights(const gaz_tensor* t, int n) override { return each([&](gaz_engine* k, int) { return k->load_weights(t, n); }); }
+    int reset_games(const int32_t* slots, int n) override {
+        if (!slots) return each([&](gaz_engine* k, int) { return k->reset_games(nullptr, 0); });
+        std::vector<std::vector<int32_t>> per(K());
+        for (int i = 0; i < n; ++i) {
+            if (slots[i] < 0 || slots[i] >= cfg.n_games) return fail("reset_games: slot out of range");
+            const int c = group_of(slots[i]); per[c].push_back(slots[i] - first[c]);
+        }
+        return each([&](gaz_engine* k, int c) { return per[c].empty() ? 0 : k->reset_games(per[c].data(), (int)per[c].size()); });
+    }
+    int run_move(int32_t* w) override { return up(kid[0], kid[0]->run_move(w)); }             // (sync_moves = 0: the group's own refusal)
+    int apply_moves(const int32_t* m) override { return up(kid[0], kid[0]->apply_moves(m)); }
+    int get_root_stats(uint32_t* N, float* W, float* P, float* pol, uint32_t* rv, float* q, int32_t* chosen, int32_t* phase) override {
+        return each([&](gaz_engine* k, int c) {
+            const size_t a = (size_t)first[c] * lay.A, g = (size_t)first[c];
+            return k->get_root_stats(N ? N + a : N, W ? W + a : W, P ? P + a : P, pol ? pol + a : pol, rv ? rv + g : rv, q ? q + g : q, chosen ? chosen + g : chosen, phase ? phase + g : phase);
+        });
+    }
+    int run_waves(int n) override {                  // wave by wave, group by group: every group's stream always holds work
+        for (int i = 0; i < n; ++i) if (each([&](gaz_engine* k, int) { return k->run_waves(1); })) return 1;
+        return 0;
+    }
+    int no_batch() { return fail("game groups hold one evaluator batch each: the wave_begin / batch API needs game_groups = 1"); }
+    int wave_begin() override { return no_batch(); }
+    int wave_end() override { return no_batch(); }
+    int batch_ptrs(void**, void**, void**) override { return no_batch(); }
+    int read_batch(int8_t*, int32_t*) override { return no_batch(); }
+    int write_outputs(const float*, const float*) override { return no_batch(); }
+    int evaluate(const int8_t* in, int n, float* p, float* v, int rep, double* ms) override { return up(kid[0], kid[0]->evaluate(in, n, p, v, rep, ms)); }
+    int record_layout(gaz_record_layout* o) override { *o = lay; return 0; }
+    int drain(void* out, int max_records, int32_t* n_out) override {
+        int total = 0;
+        for (int i = 0; i < K() && total < max_records; ++i) {       // start with another group every call: no ring starves behind a small max_records
+            gaz_engine* k = kid[(drain_from + i) % K()];
+            int32_t got = 0;
+            if (up(k, k->drain((uint8_t*)out + (size_t)total * lay.record_bytes, max_records - total, &got))) return 1;
+            total += got;
+        }
+        drain_from = (drain_from + 1) % K();
+        *n_out = total;
+        return 0;
+    }
+    int get_stats(uint64_t out[16]) override {
+        for (int i = 0; i < 16; ++i) out[i] = 0;
+        out[12] = 1;
+        for (int c = 0; c < K(); ++c) {
+            uint64_t s[16];
+            if (up(kid[c], kid[c]->get_stats(s))) return 1;
+            for (int i = 0; i < 9; ++i) out[i] += s[i];
+            out[10] += s[10]; out[13] += s[13];
+            if (s[9] > out[9]) out[9] = s[9];        // waves: every group has run the same number
+            if (!s[12]) out[12] = 0;                 // one launch per wave: only if every group runs it
+        }
+        out[14] = (uint64_t)K();
+        return 0;
+    }
+    int synchronize() override { return each([](gaz_engine* k, int) { return k->synchronize(); }); }
+    int timing_reset(int en) override { return each([&](gaz_engine* k, int) { return k->timing_reset(en); }); }
+    // sums over the groups: per wave (of all groups) the kernel time of every group's launches — they overlap in time, so the sum is NOT wall clock
+    int timing_get(double* ms_tree, double* ms_eval, double* ms_dom, int64_t* n_dom, int64_t* n_waves) override {
+        double t = 0, e = 0, d = 0; int64_t nd = 0, nw = 0;
+        for (int c = 0; c < K(); ++c) {
+            double a = 0, b = 0, x = 0; int64_t y = 0, z = 0;
+            if (up(kid[c], kid[c]->timing_get(&a, &b, &x, &y, &z))) return 1;
+            t += a; e += b; d += x; nd += y; if (z > nw) nw = z;
+        }
+        if (ms_tree) *ms_tree = t; if (ms_eval) *ms_eval = e; if (ms_dom) *ms_dom = d; if (n_dom) *n_dom = nd; if (n_waves) *n_waves = nw;
+        return 0;
+    }
+    int dominant(char* name, int cap, double* flops) override { return up(kid[0], kid[0]->dominant(name, cap, flops)); }      // per launch of one group
+    int set_position(int slot, const int32_t* a, int n) override {
+        if (slot < 0 || slot >= cfg.n_games) return fail("set_position: bad slot / history length");
+        const int c = group_of(slot);
+        return up(kid[c], kid[c]->set_position(slot - first[c], a, n));
+    }
+    int set_search_params(int it, int tau) override { return each([&](gaz_engine* k, int) { return k->set_search_params(it, tau); }); }
+    int stop_search(int s) override { return each([&](gaz_engine* k, int) { return k->stop_search(s); }); }
+    int start_search() override { return each([](gaz_engine* k, int) { return k->start_search(); }); }
+    int set_hyperparams(const gaz_search_hyperparams* hp) override { return each([&](gaz_engine* k, int) { return k->set_hyperparams(hp); }); }
+    int read_head_features(int n, float* p, float* v, int32_t* p_row, int32_t* v_row) override {
+        if (n < 0 || n > cfg.n_games) return fail("read_head_features: n must be in [0, n_games]");
+        int32_t pr = 0, vr = 0;
+        if (up(kid[0], kid[0]->read_head_features(0, nullptr, nullptr, &pr, &vr))) return 1;
+        if (p_row) *p_row = pr; if (v_row) *v_row = vr;
+        return each([&](gaz_engine* k, int c) {
+            const int nc = n - first[c] < 0 ? 0 : (n - first[c] > size_of(c) ? size_of(c) : n - first[c]);
+            return nc ? k->read_head_features(nc, p ? p + (size_t)first[c] * pr : p, v ? v + (size_t)first[c] * vr : v, nullptr, nullptr) : 0;
+        });
+    }
+    int set_fused_wave(int on) override { return each([&](gaz_engine* k, int) { return k->set_fused_wave(on); }); }
+    int debug_fused_fault(int mod) override { return each([&](gaz_engine* k, int) { return k->debug_fused_fault(mod); }); }
+    int read_positions(int32_t* n_hist, uint8_t* hist, int stride) override {
+        if (!n_hist || !hist || stride < lay.max_T) return fail("read_positions: hist must hold at least max_T actions per slot");
+        const int st = stride > lay.t_pad ? lay.t_pad : stride;      // the row stride the groups write with
+        return each([&](gaz_engine* k, int c) { return k->read_positions(n_hist + first[c], hist + (size_t)first[c] * st, stride); });
+    }
+    int repack(int32_t* n_active, int32_t* n_launch) override {      // every group packs its own live games; the sums are reported
+        int32_t a = 0, l = 0;
+        if (each([&](gaz_engine* k, int) { int32_t x = 0, y = 0; if (k->repack(&x, &y)) return 1; a += x; l += y; return 0; })) return 1;
+        if (n_active) *n_active = a; if (n_launch) *n_launch = l;
+        return 0;
+    }
+    int probe_rules(const int32_t* actions, const int32_t* n_actions, int n_pos, int stride, int8_t* b, uint8_t* l, int32_t* w, int8_t* in, int32_t* t,
+                    const float* pin, float* pout) override { return up(kid[0], kid[0]->probe_rules(actions, n_actions, n_pos, stride, b, l, w, in, t, pin, pout)); }
+};
+
+// auto (game_groups = 0): two groups where that was measured to pay (see above); GAZ_GAME_GROUPS overrides the automatic choice only
+static int choose_game_groups(const gaz_engine_config& c) {
+    if (c.game_groups != 0) return c.game_groups;
+    static const int env = getenv("GAZ_GAME_GROUPS") ? atoi(getenv("GAZ_GAME_GROUPS")) : 0;
+    const bool able = !c.sync_moves && c.evaluator != GAZ_EVAL_EXTERNAL && !(c.games_budget > 0 && c.games_budget < c.n_games);
+    if (env > 0) return (able && env <= c.n_games) ? env : 1;
+    const bool pays = c.game == GAZ_GAME_CONNECT4 && c.search == GAZ_SEARCH_PUCT && c.evaluator == GAZ_EVAL_RESNET && c.eval_cache_log2 == 0 &&
+                      c.net_blocks > 0 && c.n_games >= 3072;
+    return able && pays ? 2 : 1;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1072,15 +1248,17 @@ int gaz_engine_create(const gaz_engine_config* cfg, gaz_engine** out) {
                          "): rebuild the binding from include/gaz_engine.h";
         return 1;
     }
-    gaz_engine* h = nullptr;
-    switch (cfg->game) {
-        case GAZ_GAME_TICTACTOE: h = new EngineT<Game<GAME_TTT>>(); break;
-        case GAZ_GAME_CONNECT4: h = new EngineT<Game<GAME_C4>>(); break;
-        case GAZ_GAME_GOMOKU: h = new EngineT<Game<GAME_GMK>>(); break;
-        default: g_create_error = "unknown game id"; return 1;
+    if (cfg->game_groups < 0) { g_create_error = "game_groups must be >= 0"; return 1; }
+    const int groups = choose_game_groups(*cfg);
+    if (groups <= 1) {
+        gaz_engine* h = make_single_engine(*cfg, &g_create_error);
+        if (!h) return 1;
+        *out = h;
+        return 0;
     }
-    h->cfg = *cfg;
-    if (h->init()) { g_create_error = h->err; delete h; *out = nullptr; return 1; }
+    GroupEngine* h = new GroupEngine();
+    h->cfg = *cfg; h->cfg.game_groups = groups;
+    if (h->init()) { g_create_error = h->err; delete h; return 1; }
     *out = h;
     return 0;
 }

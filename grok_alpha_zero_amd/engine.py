@@ -19,7 +19,7 @@ EVAL_HASH, EVAL_RESNET, EVAL_EXTERNAL = 0, 1, 2
 PH_WAIT_HOST, PH_HALT, PH_IDLE = 5, 8, 9
 
 
-ABI_VERSION = 3               # GAZ_ENGINE_ABI_VERSION of include/gaz_engine.h this binding was written against
+ABI_VERSION = 4               # GAZ_ENGINE_ABI_VERSION of include/gaz_engine.h this binding was written against
 
 
 class EngineConfig(C.Structure):       # gaz_engine_config — tests/test_abi.py checks names, order and sizeof against the header
@@ -33,7 +33,7 @@ class EngineConfig(C.Structure):       # gaz_engine_config — tests/test_abi.py
                 ("gumbel_m", C.c_int32), ("c_visit", C.c_double), ("c_scale", C.c_double), ("compact_trees", C.c_int32),
                 ("single_tree", C.c_int32), ("n_opening", C.c_int32), ("opening_actions", C.c_int32 * 8),
                 ("opening_weights", C.c_double * 8), ("max_tree_sims_per_wave", C.c_int32), ("eval_cache_log2", C.c_int32), ("gumbel_stablemax", C.c_int32), ("fast_find_win", C.c_int32),
-                ("no_gumbel_noise", C.c_int32), ("first_game_seq", C.c_uint32), ("games_budget", C.c_int64), ("tau", C.c_double), ("move_time_limit", C.c_double)]
+                ("no_gumbel_noise", C.c_int32), ("first_game_seq", C.c_uint32), ("games_budget", C.c_int64), ("tau", C.c_double), ("move_time_limit", C.c_double), ("game_groups", C.c_int32)]
 
 
 class SearchHyperparams(C.Structure):  # gaz_search_hyperparams
@@ -124,7 +124,7 @@ class SelfPlayEngine:
                  evaluator=EVAL_HASH, hash_salt=0, device=0, net_blocks=0, net_filters=128, search=SEARCH_PUCT,
                  policy_is_logits=False, max_tree_sims_per_wave=0, gumbel_m=0, c_visit=50.0, c_scale=1.0,
                  compact_trees=0, single_tree=False, opening_actions=None, eval_cache_log2=0, gumbel_stablemax=False, fast_find_win=False,
-                 use_gumbel_noise=True, first_game_seq=0, games_budget=0, tau=-1.0, move_time_limit=0.0, lib_path=None):
+                 use_gumbel_noise=True, first_game_seq=0, games_budget=0, tau=-1.0, move_time_limit=0.0, game_groups=0, lib_path=None):
         self.L = load_library(lib_path)
         self.game_id = GAME_IDS[game] if isinstance(game, str) else int(game)
         self.H, self.W, self.Cc, self.A = GAME_DIMS[self.game_id]
@@ -142,7 +142,7 @@ class SelfPlayEngine:
                                 max_tree_sims_per_wave=max_tree_sims_per_wave, eval_cache_log2=int(eval_cache_log2),
                                 gumbel_stablemax=int(gumbel_stablemax), fast_find_win=int(fast_find_win),
                                 no_gumbel_noise=int(not use_gumbel_noise), first_game_seq=int(first_game_seq), games_budget=int(games_budget),
-                                tau=float(tau), move_time_limit=float(move_time_limit or 0.0))
+                                tau=float(tau), move_time_limit=float(move_time_limit or 0.0), game_groups=int(game_groups))
         for i, (a, w) in enumerate(opening_actions or []):       # [(action index, weight)] — train_config["opening_actions"]
             self.cfg.opening_actions[i] = int(a); self.cfg.opening_weights[i] = float(w); self.cfg.n_opening = i + 1
         self.h = C.c_void_p()
@@ -306,7 +306,7 @@ class SelfPlayEngine:
         out = (C.c_uint64 * 16)()
         self._ck(self.L.gaz_engine_get_stats(self.h, out))
         s = [int(x) for x in out]
-        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11], fused_wave=s[12], fused_faults=s[13])
+        return dict(game_stats=np.array(s[:6], np.uint64), evals=s[6], sims=s[7], plies=s[8], waves=s[9], cache_hits=s[10], pipeline_groups=s[11], fused_wave=s[12], fused_faults=s[13], game_groups=max(int(s[14]), 1))
 
     def drain_finished(self, max_records=None):
         """Finished games as dicts: actions, policies [T,A], q, z, values (=0.5(z+q), Self_Play.py:165-172),

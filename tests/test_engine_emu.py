@@ -311,3 +311,71 @@ def test_bench_random_histories_are_legal_and_unfinished():
                 assert g.check_win() == -2 if g.action_history else True
                 g.do_action(GAMES[game].index_to_action(int(a)))
             assert not h or g.check_win() == -2
+
+
+@pytest.mark.parametrize("search,groups,G,budget", [("puct", 2, 10, 27), ("puct", 3, 11, 11), ("gumbel", 2, 9, 20)])
+def test_emu_game_groups_play_exactly_the_games_of_one_batch(emu_lib, oracle, search, groups, G, budget):
+    """gaz_engine_config::game_groups (round 3): K groups of consecutive slots, each an engine of its own (stream, batch, launch per wave) behind ONE
+    handle.  No game may depend on it: with a games_budget that is no multiple of n_games and uneven group sizes, the grouped engine plays exactly
+    the (slot, game_seq) set of one batch, every record equal to the oracle's; counters are sums; per-slot calls reach the right group."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, SEARCH_GUMBEL, SEARCH_PUCT
+    iters = 16
+    kw = dict(search=SEARCH_GUMBEL, gumbel_m=4, c_visit=50.0, c_scale=1.0) if search == "gumbel" else dict(search=SEARCH_PUCT)
+    out = {}
+    for k in (1, groups):
+        eng = SelfPlayEngine("Connect4", G, iters, 42, 4, 3, 2.5, 0.5, seed=21, hash_salt=5, slot_offset=100, ring_capacity=4 * G, games_budget=budget,
+                             game_groups=k, lib_path=emu_lib, **kw)
+        recs = []
+        for _ in range(4000):
+            eng.run_waves(8)
+            recs += eng.drain_finished(3)                  # a small max_records: no group's ring may starve
+            if len(recs) == budget:
+                break
+        st = eng.stats()
+        assert st["game_groups"] == k and len(recs) == budget
+        assert st["game_stats"][2] == budget and st["plies"] == sum(r["T"] for r in recs)
+        out[k] = ({(r["slot"], r["game_seq"]): r for r in recs}, st)
+        eng.close()
+    one, many = out[1][0], out[groups][0]
+    assert set(one) == set(many) == {(100 + g, q) for q in range(8) for g in range(G) if q * G + g < budget}
+    for key in one:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T", "values"):
+            np.testing.assert_array_equal(np.asarray(one[key][f]), np.asarray(many[key][f]), err_msg=f"{key} {f}")
+    assert out[1][1]["evals"] == out[groups][1]["evals"] and out[1][1]["sims"] == out[groups][1]["sims"]
+    for (slot, seq) in list(one)[:4]:
+        o = (oracle.selfplay_game_gumbel("Connect4", iters, 42, 4, 50.0, 1.0, 21, slot, seq, hash_salt=5) if search == "gumbel"
+             else oracle.selfplay_game("Connect4", iters, 42, 4, 3, 2.5, 0.5, 21, slot, seq, hash_salt=5))
+        np.testing.assert_array_equal(many[(slot, seq)]["actions"], o["actions"])
+        np.testing.assert_array_equal(many[(slot, seq)]["root_N"], o["root_N"])
+
+
+def test_emu_game_groups_route_per_slot_calls_and_refuse_what_they_cannot_serve(emu_lib):
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_EXTERNAL
+    mk = lambda k, **kw: SelfPlayEngine("Connect4", 7, 16, 42, 8, 7, 2.5, 0.5, seed=3, hash_salt=1, game_groups=k, lib_path=emu_lib, **kw)
+    a, b = mk(1), mk(3)                                    # groups of 3 | 2 | 2 slots
+    hs = [[3], [], [0, 1, 2], [6, 6], [], [2, 3, 4, 5], [1]]
+    for e in (a, b):
+        for g, h in enumerate(hs):
+            if h:
+                e.set_position(g, h)
+        e.run_waves(40)
+    pa, pb = a.read_positions(), b.read_positions()
+    assert pa == pb and all(pb[g][:len(hs[g])] == hs[g] for g in range(7))
+    sa, sb = a.root_stats(), b.root_stats()
+    for k in sa:
+        np.testing.assert_array_equal(np.asarray(sa[k]), np.asarray(sb[k]), err_msg=k)
+    b.reset_games([1, 4, 6])
+    a.reset_games([1, 4, 6])
+    a.run_waves(3); b.run_waves(3)
+    assert a.read_positions() == b.read_positions()
+    with pytest.raises(RuntimeError, match="game_groups"):
+        b.wave_begin()
+    a.close(); b.close()
+    with pytest.raises(RuntimeError, match="game_groups"):
+        mk(2, sync_moves=True)
+    with pytest.raises(RuntimeError, match="game_groups"):
+        mk(2, evaluator=EVAL_EXTERNAL)
+    with pytest.raises(RuntimeError, match="game_groups"):
+        mk(8)
+    with pytest.raises(RuntimeError, match="games_budget"):
+        mk(2, games_budget=5)

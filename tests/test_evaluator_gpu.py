@@ -453,6 +453,41 @@ def test_fused_tree_and_trunk_launch_gives_identical_games(search, monkeypatch):
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
 
 
+@pytest.mark.parametrize("groups,fault", [(2, False), (3, False), (2, True)])
+def test_game_groups_with_fused_launches_in_flight_together_give_identical_games(groups, fault):
+    """gaz_engine_config::game_groups (engine.hip GroupEngine, round 3): the games as K groups, each with its own stream, batch and fused tree + trunk
+    launch per wave — K launches in flight on the chip at once, each one's trunk workgroups polling only their own group's completion queue.
+    Scheduling only: with a games_budget the grouped engine must finish exactly the games of one batch, bit for bit — also while workgroups of the
+    concurrent launches give up waiting (gaz_engine_debug_fused_fault) and the groups fall back to separate launches."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=5).eval().export_engine_weights()
+    G, budget = 1600, 2000
+    got = []
+    for k in (groups, 1):
+        eng = SelfPlayEngine("Connect4", G, 24, 14, 4, 3, 2.5, 0.5, seed=29, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192, games_budget=budget, game_groups=k)
+        eng.load_weights(w)
+        eng.run_waves(30); eng.synchronize()
+        st = eng.stats()
+        assert st["game_groups"] == k and st["fused_wave"] == 1, st
+        if fault and k > 1:
+            eng.debug_fused_fault(5)
+            eng.run_waves(24)
+            st = eng.stats()
+            assert st["fused_faults"] >= 24 * k and st["fused_wave"] == 0, st
+        for _ in range(60):
+            eng.run_waves(100)
+            if eng.stats()["game_stats"][2] >= budget:
+                break
+        got.append({(r["slot"], r["game_seq"]): r for r in eng.drain_finished(8192)})
+        eng.close()
+    a, b = got
+    assert len(a) == budget and set(a) == set(b)
+    for key in a:
+        for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
+            np.testing.assert_array_equal(np.asarray(a[key][f]), np.asarray(b[key][f]), err_msg=f"{key} {f}")
+
+
 @pytest.mark.parametrize("cache", [0, 16])
 def test_fused_launch_bounded_wait_recovers_without_changing_games(cache):
     """The fused launch's hand-over is bounded (trunk.hpp TrunkArgs::spin_ticks; ADVICE r2 / VERDICT r2 item 5): a trunk workgroup whose games'
