@@ -49,6 +49,8 @@ def parse(argv=None):
     ap.add_argument("--ref-convention-leg", type=int, default=-1, help="1: extra leg at int(1.5 * sims) simulations per move, what Self_Play passes for MCTS_iteration_limit = sims (Self_Play.py:99); default on for the connect4 config at N = 1")
     ap.add_argument("--other-configs", type=int, default=-1, help="1: also measure BASELINE configs[4] (Gumbel) and configs[3] (Gomoku) and append them to the line as "
                                                                   "'gumbel' / 'gomoku' objects (default: on for the plain headline command at N = 1)")
+    ap.add_argument("--game-groups", type=int, default=0, help="gaz_engine_config::game_groups of the measured engines: 0 = the library's choice (2 for the headline config), "
+                                                               "1 = one batch, K = K batches with their launches in flight together")
     ap.add_argument("--burn-in-waves", type=int, default=-1, help="untimed waves before the warm-up steps (default: about two game lengths for the Connect4 configs — 8000 PUCT / "
                                                                   "2400 Gumbel waves: from the lockstep start the ply mix of 4096 games settles to its stationary state within 16 x 400 waves, "
                                                                   "tools/ts_probe.py; 0 for Gomoku, whose games last minutes)")
@@ -308,12 +310,12 @@ def main():
         stagger = args.stagger if args.stagger >= 0 else int(game == "Gomoku")
         burn = args.burn_in_waves if args.burn_in_waves >= 0 else (0 if (game != "Connect4" or emu) else (2400 if gumbel else 8000))
 
-        def make_engine(n_sims, cache_log2):
+        def make_engine(n_sims, cache_log2, groups=None):
             e = SelfPlayEngine(game, G, n_sims, max_actions, ef, es, cpuct, alpha, seed=1234, slot_offset=rank * G, device=0 if emu else local,
                                evaluator=EVAL_RESNET if use_net else EVAL_HASH, net_blocks=blocks if use_net else 0,
                                hash_salt=7, ring_capacity=0, search=SEARCH_GUMBEL if gumbel else SEARCH_PUCT, gumbel_m=gm,
                                c_visit=50.0, c_scale=1.0, policy_is_logits=gumbel, max_tree_sims_per_wave=args.max_tree_sims,
-                               eval_cache_log2=cache_log2, lib_path=args.emu_lib or None)
+                               eval_cache_log2=cache_log2, game_groups=args.game_groups if groups is None else groups, lib_path=args.emu_lib or None)
             if use_net:
                 e.load_weights(weights)
             if stagger:
@@ -367,19 +369,38 @@ def main():
         tm = eng.timing()
         kname, kflops = eng.dominant_kernel()
         fused = bool(eng.stats().get("fused_wave"))
-        tm_fused, kname_fused = None, None
+        groups = int(eng.stats().get("game_groups", 1))
+        tm_fused, kname_fused, tm_groups = None, None, None
+        keng = eng                                              # the engine the per-kernel segments run on
+        if groups > 1 and use_net:
+            # The headline segment ran the games as `groups` batches with their launches in flight TOGETHER (gaz_engine_config::game_groups): the
+            # durations of overlapping kernels price nothing.  The per-kernel numbers (roofline, roofline_tree, the fused launch) are therefore
+            # taken on ONE batch of all the games — the launch shape the rocprofv3 summaries under profiles/ show — on a second engine brought to
+            # the same steady state: same games, bit for bit.
+            tm_groups = tm
+            eng.timing_reset(False)
+            keng = make_engine(sims, args.eval_cache, groups=1)
+            for i in range(0, burn, 500):
+                keng.run_waves(min(500, burn - i)); keng.synchronize()
+            keng.timing_reset(True)
+            keng.run_waves(args.waves_per_step); keng.synchronize()
+            tm = keng.timing()
+            kname, kflops = keng.dominant_kernel()
+            log(f"[{config}] one-batch engine for the per-kernel segments ready")
         if fused and use_net:
             # The headline segment ran the tree step and the trunk kernel as ONE launch (k_wave_trunk): its duration includes the part of
             # the tree step it could not hide, so it does not price the MFMA kernel.  Time the trunk kernel on its own in a second
             # segment of this run: same engine, same games, tree step and trunk launched separately (results are bit-identical).
             tm_fused, kname_fused = tm, kname
-            eng.set_fused_wave(False)
-            eng.timing_reset(True)
-            eng.run_waves(args.waves_per_step); eng.synchronize()
-            tm = eng.timing()
-            kname, kflops = eng.dominant_kernel()
-            eng.set_fused_wave(True)
-        eng.timing_reset(False)
+            keng.set_fused_wave(False)
+            keng.timing_reset(True)
+            keng.run_waves(args.waves_per_step); keng.synchronize()
+            tm = keng.timing()
+            kname, kflops = keng.dominant_kernel()
+            keng.set_fused_wave(True)
+        keng.timing_reset(False)
+        if keng is not eng:
+            keng.close()
         t_red = time.perf_counter()
         total = reduce_stats(delta[:5], world)                  # the one collective of the path: counters only
         t_red = time.perf_counter() - t_red
@@ -421,11 +442,21 @@ def main():
                 if tm_fused is not None and tm_fused["n_dominant"] > 0:
                     f_ms = tm_fused["ms_dominant"] / tm_fused["n_dominant"]
                     roof["measured_in"] = (f"a second timed segment of this run ({args.waves_per_step} waves, HIP events on every 8th) with the tree step and the "
-                                           "trunk launched as separate kernels; the headline segment runs them as ONE launch, see fused_launch")
+                                           "trunk launched as separate kernels; the headline segment runs them as ONE launch, see fused_launch" +
+                                           ("; both on ONE batch of all the games (game_groups = 1, a second engine in the same steady state), see game_groups" if tm_groups else ""))
                     roof["fused_launch"] = dict(kernel=kname_fused, avg_launch_us=f_ms * 1e3, launches=int(tm_fused["n_dominant"]),
                                                 frac_if_priced_as_mfma_only=kflops / (f_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                                 note="duration of tree step + trunk in one launch during the headline segment: the tree step's "
                                                      "slowest games (a latency-bound pointer chase) are partly hidden behind the trunk's first workgroups")
+                if tm_groups is not None and tm_groups["n_dominant"] > 0:
+                    g_ms = tm_groups["ms_dominant"] / tm_groups["n_dominant"]
+                    wave_us = dt / max(steps * args.waves_per_step, 1) * 1e6
+                    roof["game_groups"] = dict(groups=groups, launch_us_per_group=g_ms * 1e3, wave_us_all_groups=wave_us,
+                                               trunk_kernel_alone_us=roof["avg_launch_us"], wave_over_trunk_alone=wave_us / roof["avg_launch_us"],
+                                               note=f"headline segment: the games run as {groups} batches, each with its own stream and ONE launch (tree step + trunk) per wave, "
+                                                    f"{groups} launches in flight together — a group's trunk tiles fill the chip while the other group's tree step starts and its heads "
+                                                    "run.  launch_us_per_group is the duration of one group's launch while it shares the chip (overlapping: not a price); "
+                                                    "wave_us_all_groups is wall clock per wave of all games; trunk_kernel_alone_us the MFMA kernel over all games on an otherwise idle chip")
             # the tree kernel against ITS roofline (north_star: "rocprof HBM GB/s on tree kernels"): algorithmic bytes per launch = SURVEY 8d's bytes per
             # simulation x the simulations one launch runs (measured), over the launch duration of the separately-launched tree step (HIP events);
             # counter bytes from the committed --pmc passes.  It is a chain of dependent round trips, not a stream: the fraction says so.
@@ -471,10 +502,10 @@ def main():
                                    evals_per_position=evals / max(positions, 1), evals_per_s=evals / dt, sims_per_s=n_sims / dt,
                                    eval_cache_log2=args.eval_cache, eval_cache_hits=hits,
                                    eval_tflops=(evals - hits) * fl["total"] / dt / 1e12,
-                                   fused_tree_and_trunk_launch=fused, fused_launch_faults=faults,
+                                   fused_tree_and_trunk_launch=fused, fused_launch_faults=faults, game_groups=groups,
                                    ms_tree_kernel_per_wave=tm["ms_tree"] / tw,
                                    ms_evaluator_per_wave=tm["ms_eval"] / tw,
-                                   per_wave_note=("tree / evaluator ms per wave come from the unfused timing segment" if tm_fused is not None else None)),
+                                   per_wave_note=(("tree / evaluator ms per wave come from the unfused timing segment" + (" on one batch of all the games" if tm_groups else "")) if tm_fused is not None else None)),
                        roofline=roof, roofline_tree=roof_tree)
 
         # ---- extra legs (never the headline value) -------------------------------------------------------------------------

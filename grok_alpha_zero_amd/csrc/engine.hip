@@ -538,7 +538,7 @@ template <class G> struct EngineT : gaz_engine {
         const bool gumbel = cfg.search == GAZ_SEARCH_GUMBEL;
         // round 3: Gomoku's PUCT search as well (one game per wavefront; compacting trees are fine: a game's state lives in HBM either way).  GAZ_FUSE_GOMOKU=0 -> separate
         const bool gmk = G::ID == GAME_GMK && !gumbel && !E.cache && !(getenv("GAZ_FUSE_GOMOKU") && atoi(getenv("GAZ_FUSE_GOMOKU")) == 0);
-        const bool c4 = G::ID == GAME_C4 && WAVE / GP::TEAM == 4 && !E.compact && !(E.cache && !with_cache);
+        const bool c4 = G::ID == GAME_C4 && WAVE / GP::TEAM >= 4 && !E.compact && !(E.cache && !with_cache);
         if (off || !(c4 || gmk) || !eval || !eval->supports_split()) return false;
         // round 3: the Gumbel search too (BASELINE configs[4]; its tree step is 17 % of a wave when launched separately).  GAZ_FUSE_GUMBEL=0 -> separate
         if (gumbel && ((getenv("GAZ_FUSE_GUMBEL") && atoi(getenv("GAZ_FUSE_GUMBEL")) == 0) || E.cache)) return false;
@@ -1066,7 +1066,7 @@ template <class G> struct EngineT : gaz_engine {
 // first boards, the last round of tiles leaves slots idle and the heads (Dense-1 + tail, ~27 us) run on a nearly empty chip.  With TWO launches
 // of half the games in flight, the other group's trunk tiles fill all of that: Connect4 headline config, steady state, one box: 7.84 M -> 8.60 M
 // evaluations/s with 2048 | 2048 (2560 | 1536: 8.14 M; 3072 | 1024: 7.19 M; three groups 7.73 M; four 7.1 M; Gumbel 8192 -> 2 x 4096: -1 %;
-// Gomoku 2 x 1024: -10 %) — so auto = 2 only for Connect4 PUCT + ResNet from 3072 games.
+// Gomoku 2 x 1024: -10 %; 8-lane teams = half the tree blocks: +0.5 %, within noise, not kept) — so auto = 2 only for Connect4 PUCT + ResNet from 3072 games.
 static gaz_engine* make_single_engine(const gaz_engine_config& cfg, std::string* err) {
     gaz_engine* h = nullptr;
     switch (cfg.game) {
@@ -1103,6 +1103,9 @@ struct GroupEngine : gaz_engine {
             gaz_engine_config cc = cfg;
             cc.n_games = size_of(c); cc.slot_offset = cfg.slot_offset + (uint32_t)first[c];
             if (cfg.ring_capacity > 0) cc.ring_capacity = (int32_t)(((int64_t)cfg.ring_capacity * cc.n_games + n - 1) / n);
+            // with another group's trunk tiles filling the chip, the tail of a group's tree step costs less than the rows that carry no request:
+            // two groups, headline config, one box (tools/sweep_groups.sh): 8: 66.8 k, 12: 67.5 k, 16: 67.4 k positions/s (one batch: 8, see EngineT::init)
+            if (cfg.max_tree_sims_per_wave == 0 && cfg.game == GAZ_GAME_CONNECT4 && cfg.search == GAZ_SEARCH_PUCT && cfg.evaluator == GAZ_EVAL_RESNET) cc.max_tree_sims_per_wave = 12;
             if (cfg.games_budget > 0) {
                 // one engine: slot g plays its k-th game iff k n + g < budget, i.e. floor(budget / n) games and one more in the first budget % n slots;
                 // the group's own rule (k n_c + g_c < budget_c) gives exactly those games with this budget
@@ -1228,8 +1231,8 @@ static int choose_game_groups(const gaz_engine_config& c) {
     static const int env = getenv("GAZ_GAME_GROUPS") ? atoi(getenv("GAZ_GAME_GROUPS")) : 0;
     const bool able = !c.sync_moves && c.evaluator != GAZ_EVAL_EXTERNAL && !(c.games_budget > 0 && c.games_budget < c.n_games);
     if (env > 0) return (able && env <= c.n_games) ? env : 1;
-    const bool pays = c.game == GAZ_GAME_CONNECT4 && c.search == GAZ_SEARCH_PUCT && c.evaluator == GAZ_EVAL_RESNET && c.eval_cache_log2 == 0 &&
-                      c.net_blocks > 0 && c.n_games >= 3072;
+    // (with the evaluation cache every group has a table of its own — nothing is shared between groups: 108.2 k -> 110.2 k positions/s)
+    const bool pays = c.game == GAZ_GAME_CONNECT4 && c.search == GAZ_SEARCH_PUCT && c.evaluator == GAZ_EVAL_RESNET && c.net_blocks > 0 && c.n_games >= 3072;
     return able && pays ? 2 : 1;
 }
 
