@@ -1147,7 +1147,20 @@ struct GroupEngine : gaz_engine {
     int batch_ptrs(void**, void**, void**) override { return no_batch(); }
     int read_batch(int8_t*, int32_t*) override { return no_batch(); }
     int write_outputs(const float*, const float*) override { return no_batch(); }
-    int evaluate(const int8_t* in, int n, float* p, float* v, int rep, double* ms) override { return up(kid[0], kid[0]->evaluate(in, n, p, v, rep, ms)); }
+    // rows [first[c], first[c + 1]) go through group c's evaluator (and stay in ITS head-feature buffers: read_head_features below); ms: the sum
+    int evaluate(const int8_t* in, int n, float* p, float* v, int rep, double* ms) override {
+        if (n < 1 || n > cfg.n_games) return fail("evaluate: n must be in [1, n_games]");
+        const size_t row = cfg.game == GAZ_GAME_TICTACTOE ? Game<GAME_TTT>::HW * Game<GAME_TTT>::C : (cfg.game == GAZ_GAME_CONNECT4 ? Game<GAME_C4>::HW * Game<GAME_C4>::C : Game<GAME_GMK>::HW * Game<GAME_GMK>::C);
+        double total = 0;
+        if (each([&](gaz_engine* k, int c) {
+                const int nc = n - first[c] < 0 ? 0 : (n - first[c] > size_of(c) ? size_of(c) : n - first[c]);
+                double m = 0;
+                if (nc && k->evaluate(in + (size_t)first[c] * row, nc, p ? p + (size_t)first[c] * lay.A : p, v ? v + first[c] : v, rep, &m)) return 1;
+                total += m; return 0;
+            })) return 1;
+        if (ms) *ms = total;
+        return 0;
+    }
     int record_layout(gaz_record_layout* o) override { *o = lay; return 0; }
     int drain(void* out, int max_records, int32_t* n_out) override {
         int total = 0;

@@ -392,7 +392,7 @@ def test_hip_evaluation_cache_gives_identical_games(G, ring):
     got = []
     for log2 in (0, 16):
         eng = SelfPlayEngine("Connect4", G, 32, 16, 4, 3, 2.5, 0.5, seed=21, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=ring,
-                             eval_cache_log2=log2)
+                             eval_cache_log2=log2, game_groups=1)
         eng.load_weights(w)
         eng.run_waves(900); eng.synchronize()
         st = eng.stats()

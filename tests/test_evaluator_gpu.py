@@ -9,7 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _mk(n_games, blocks, randomize_bn, seed=0):
+def _mk(n_games, blocks, randomize_bn, seed=0, game_groups=1):
+    """an engine as a carrier of the evaluator: ONE batch (game_groups = 1), so that evaluate(n rows) is one launch over n rows"""
     import torch
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
     from grok_alpha_zero_amd.net import Connect4Net
@@ -17,7 +18,7 @@ def _mk(n_games, blocks, randomize_bn, seed=0):
     if randomize_bn:
         net.randomize_bn()
     eng = SelfPlayEngine("Connect4", n_games, 200, 42, 8, 7, 2.5, 0.5, seed=1, evaluator=EVAL_RESNET, net_blocks=blocks,
-                         ring_capacity=2 * n_games)
+                         ring_capacity=2 * n_games, game_groups=game_groups)
     eng.load_weights(net.export_engine_weights())
     return net, eng
 
@@ -451,6 +452,25 @@ def test_fused_tree_and_trunk_launch_gives_identical_games(search, monkeypatch):
     for k in a:
         for f in ("actions", "root_N", "root_W", "root_P", "policies", "q", "evals", "root_visits", "winner", "T"):
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
+
+
+def test_game_groups_evaluate_and_head_features_cover_all_rows():
+    """gaz_engine_evaluate / gaz_engine_read_head_features on a grouped engine: rows [first[c], first[c + 1]) go through group c — the outputs must be
+    those of one batch, row for row (rows are independent of the batch they are evaluated in)."""
+    rng = np.random.default_rng(5)
+    x = _random_states(1000, rng)
+    outs = []
+    for k in (1, 3):
+        net, eng = _mk(1000, 2, True, seed=3, game_groups=k)
+        p, v, _ = eng.evaluate(x)
+        q, u, _ = eng.evaluate(x[:700])                    # a prefix that ends inside the last group
+        pf, vf = eng.head_features(700)
+        outs.append((p, v, q, u, pf.copy(), vf.copy()))
+        assert eng.stats()["game_groups"] == k
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.array_equal(outs[0][0][:700], outs[0][2])
 
 
 @pytest.mark.parametrize("groups,fault", [(2, False), (3, False), (2, True)])
