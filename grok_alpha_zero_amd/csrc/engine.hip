@@ -254,6 +254,7 @@ template <class G> GAZ_KERNEL k_count(DevParams<G> E, int32_t* out) {   // out[0
 struct gaz_engine {
     gaz_engine_config cfg;
     std::string err;
+    int grouped = 0;                                 // > 1: this engine is one of that many game groups of a GroupEngine (launch-shape defaults differ)
     virtual ~gaz_engine() {}
     int fail(const std::string& m) { err = m; return 1; }
     virtual int init() = 0;
@@ -631,7 +632,9 @@ template <class G> struct EngineT : gaz_engine {
                     static const int rounds_env = getenv("GAZ_FUSE_TREE_ROUNDS") ? atoi(getenv("GAZ_FUSE_TREE_ROUNDS")) : 0;
                     // measured on one box (tools/sweep_rounds.sh): PUCT 1 round 56.6 k positions/s, 2 rounds 54.6 k, 4: 53.8 k; Gumbel (8192 games: every slot
                     // starts as a tree block) 1: 314 k, 2: 319 k, 4: 321 k, 8: 317 k
-                    const int rounds = rounds_env > 0 ? rounds_env : (G::ID == GAME_GMK ? 8 : (cfg.search == GAZ_SEARCH_GUMBEL ? 4 : 1));
+                    // Gomoku as one of two game groups (tools/sweep_groups5.sh): 2: 2372, 3: 2372, 4: 2384, 6: 2357, 8: 2330 positions/s
+                    // Gumbel as one of two game groups of 4096 (tools/sweep_groups6.sh, sweep_groups7.sh, one box): 1: 341.3 k, 2: 344.2 k, 4: 321.4 k, 8: 247.5 k (one batch: 323.9 k)
+                    const int rounds = rounds_env > 0 ? rounds_env : (G::ID == GAME_GMK ? (this->grouped > 1 ? 4 : 8) : (cfg.search == GAZ_SEARCH_GUMBEL ? (this->grouped > 1 ? 2 : 4) : 1));
                     const int gpb = G::ID == GAME_GMK ? rounds * 8 : rounds * 4 * ((cfg.search == GAZ_SEARCH_GUMBEL && !gumbel_teams) ? 1 : WAVE / GPq::TEAM);
                     Ef.done_queue = d_queue; Ef.queue_gpb = gpb; Ef.queue_nfull = n_eff / gpb; Ef.queue_rem = n_eff % gpb;
                 }
@@ -1065,8 +1068,10 @@ template <class G> struct EngineT : gaz_engine {
 // Why: a wave of one engine is tree step -> trunk -> heads in sequence; in the one-launch form the trunk workgroups still wait ~60 us for their
 // first boards, the last round of tiles leaves slots idle and the heads (Dense-1 + tail, ~27 us) run on a nearly empty chip.  With TWO launches
 // of half the games in flight, the other group's trunk tiles fill all of that: Connect4 headline config, steady state, one box: 7.84 M -> 8.60 M
-// evaluations/s with 2048 | 2048 (2560 | 1536: 8.14 M; 3072 | 1024: 7.19 M; three groups 7.73 M; four 7.1 M; Gumbel 8192 -> 2 x 4096: -1 %;
-// Gomoku 2 x 1024: -10 %; 8-lane teams = half the tree blocks: +0.5 %, within noise, not kept) — so auto = 2 only for Connect4 PUCT + ResNet from 3072 games.
+// evaluations/s with 2048 | 2048 (2560 | 1536: 8.14 M; 3072 | 1024: 7.19 M; three groups 7.73 M; four 7.1 M;
+// 8-lane teams = half the tree blocks: +0.5 %, within noise, not kept).  Gomoku 2048 games -> 2 x 1024: +6 % (+8.6 % with four tree rounds per block).
+// Gumbel 8192 -> 2 x 4096 with two tree rounds per block: +6 %.  auto = 2 for Connect4 PUCT + ResNet from 3072 games, Gomoku PUCT + ResNet from
+// 2048 games, Connect4 Gumbel + ResNet from 6144 games.
 static gaz_engine* make_single_engine(const gaz_engine_config& cfg, std::string* err) {
     gaz_engine* h = nullptr;
     switch (cfg.game) {
@@ -1115,6 +1120,7 @@ struct GroupEngine : gaz_engine {
             std::string e;
             gaz_engine* h = make_single_engine(cc, &e);
             if (!h) return fail("game group " + std::to_string(c) + ": " + e);
+            h->grouped = k;
             kid.push_back(h);
         }
         return kid[0]->record_layout(&lay);
@@ -1246,7 +1252,13 @@ static int choose_game_groups(const gaz_engine_config& c) {
     if (env > 0) return (able && env <= c.n_games) ? env : 1;
     // (with the evaluation cache every group has a table of its own — nothing is shared between groups: 108.2 k -> 110.2 k positions/s)
     const bool pays = c.game == GAZ_GAME_CONNECT4 && c.search == GAZ_SEARCH_PUCT && c.evaluator == GAZ_EVAL_RESNET && c.net_blocks > 0 && c.n_games >= 3072;
-    return able && pays ? 2 : 1;
+    // Gomoku (2048 games, 10 blocks; the one-launch wave needs the cache off): 2195 -> 2330 positions/s, 2384 with four tree rounds per block
+    // (EngineT::one_wave); from empty boards 1706 -> 1855.  Three groups 2225.  Its heads are a chain of small kernels (~300 us of a 3000-us wave)
+    // that one batch runs on an idle chip
+    const bool pays_gmk = c.game == GAZ_GAME_GOMOKU && c.search == GAZ_SEARCH_PUCT && c.evaluator == GAZ_EVAL_RESNET && c.net_blocks > 0 && c.eval_cache_log2 == 0 && c.n_games >= 2048;
+    // Gumbel (8192 games -> 2 x 4096, two tree rounds per block instead of four): 323.9 k -> 344.1 k positions/s same box (with four rounds: -1 %)
+    const bool pays_gumbel = c.game == GAZ_GAME_CONNECT4 && c.search == GAZ_SEARCH_GUMBEL && c.evaluator == GAZ_EVAL_RESNET && c.net_blocks > 0 && c.eval_cache_log2 == 0 && c.n_games >= 6144;
+    return able && (pays || pays_gmk || pays_gumbel) ? 2 : 1;
 }
 
 // ------------------------------------------------------------------------------------------ C ABI

@@ -1085,6 +1085,8 @@ struct GenericEvaluator : Evaluator {
         if (timing) hipEventRecord(e1, s);
         trunk_out = cur; fuse_heads = fuse;
     }
+    // (measured and dropped, round 3: the heads on high-priority streams of their own, forked from / joined to the caller's stream — with two game
+    // groups 2160 instead of 2312 positions/s: the priority kernels break into the other group's trunk rounds, and two more event hops per wave)
     void forward_heads(hipStream_t s, float* policy, float* value, int n, int) override {
         if (!loaded) return;
         const int M = n * HW;

@@ -113,7 +113,7 @@ typedef struct {
                                      stream, evaluator batch and launch per wave, stepped alternately: the trunk tiles of one group fill the chip while
                                      another group's tree step starts or its heads run (continuous self-play with a built-in evaluator only; the
                                      wave_begin / batch API is refused).  1 = one batch.  0 = automatic: 2 where measured to pay (Connect4 PUCT +
-                                     ResNet from 3072 games: +9.7 % evaluations/s), else 1.  With the evaluation cache every group keeps a table of its own */
+                                     ResNet from 3072 games: +9.7 % evaluations/s; Gomoku PUCT + ResNet from 2048 games: +8.6 %; Connect4 Gumbel + ResNet from 6144 games: +6 %), else 1.  With the evaluation cache every group keeps a table of its own */
 } gaz_engine_config;
 
 /* MCTS.update_hyperparams(**kwargs) (MCTS.py:134-168) / MCTS_Gumbel.update_hyperparams (MCTS_Gumbel.py:186-210): values take
