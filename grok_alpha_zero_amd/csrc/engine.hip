@@ -255,6 +255,7 @@ struct gaz_engine {
     gaz_engine_config cfg;
     std::string err;
     int grouped = 0;                                 // > 1: this engine is one of that many game groups of a GroupEngine (launch-shape defaults differ)
+    virtual void note_grouped() {}
     virtual ~gaz_engine() {}
     int fail(const std::string& m) { err = m; return 1; }
     virtual int init() = 0;
@@ -437,6 +438,8 @@ template <class G> struct EngineT : gaz_engine {
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
+
+    void note_grouped() override { if (eval) eval->set_shared_chip(this->grouped > 1); }
 
     int check_device_error() {
         int32_t code = 0;
@@ -1120,7 +1123,7 @@ struct GroupEngine : gaz_engine {
             std::string e;
             gaz_engine* h = make_single_engine(cc, &e);
             if (!h) return fail("game group " + std::to_string(c) + ": " + e);
-            h->grouped = k;
+            h->grouped = k; h->note_grouped();
             kid.push_back(h);
         }
         return kid[0]->record_layout(&lay);

@@ -34,6 +34,9 @@ struct Evaluator {
     // planes of board b are valid once ready[b] == epoch (FuseHandoff, below).  Null = this evaluator / configuration cannot be fused.
     virtual const void* trunk_plan(const int8_t* in, int n, int p0, const struct FuseHandoff& h) { (void)in; (void)n; (void)p0; (void)h; return nullptr; }
     virtual bool plan_uses_queue(const void* plan) const { (void)plan; return false; }      // did trunk_plan take FuseHandoff::queue on?
+    // this evaluator serves ONE of several game groups whose launches share the chip (engine.hip GroupEngine): tile rounds of a single launch
+    // need not come out even — another group's tiles fill the slots — so the plan may take the more efficient tile shape throughout
+    virtual void set_shared_chip(bool on) { (void)on; }
     virtual bool ready() const { return true; }
     virtual void timing_reset() {}
     virtual void timing_get(double* ms, int64_t* launches) { *ms = 0; *launches = 0; }

@@ -612,9 +612,12 @@ struct ResNetEvaluator : Evaluator {
         bool mix = false;
         if (trunk_mix && 96 / HW >= 1 && 96 / HW < 128 / HW) {    // whole rounds of 128-row tiles, the rest in 96-row tiles (k_trunk_mix)
             const int slots = 2 * n_cus, bb = 128 / HW, sb = 96 / HW;
-            const int nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
+            int nb = (n / (bb * slots)) * slots, ns = (n - nb * bb + sb - 1) / sb;
             const double cost_mix = nb / slots + 0.78 * ((ns + slots - 1) / slots), cost_big = (nwg + slots - 1) / slots;
-            if (cost_mix < cost_big) { mix = true; r.n_big = nb; r.small_rows = sb * HW; nwg = nb + ns; }
+            // one of several game groups: the other groups' tiles fill a ragged last round, so every board that fits one goes into a 3-board tile
+            // (46 us per board and slot against 51 in a 2-board tile) and only the remainder into 2-board tiles
+            if (shared_chip && perm_big && perm_small) { nb = n / bb; ns = (n - nb * bb + sb - 1) / sb; }
+            if (cost_mix < cost_big || (shared_chip && perm_big && perm_small)) { mix = true; r.n_big = nb; r.small_rows = sb * HW; nwg = nb + ns; }
         }
         P.nwg = nwg; P.mix = mix; P.lds_bytes = (unsigned)trunk_lds_bytes(128);
         return true;
@@ -628,6 +631,8 @@ struct ResNetEvaluator : Evaluator {
         return &fused_plan;
     }
     bool plan_uses_queue(const void* plan) const override { return plan && static_cast<const TrunkLaunchPlan*>(plan)->args.queue != nullptr; }
+    bool shared_chip = false;
+    void set_shared_chip(bool on) override { static const bool off = getenv("GAZ_GROUP_BIG_TILES") && atoi(getenv("GAZ_GROUP_BIG_TILES")) == 0; shared_chip = on && !off; }
     int round_rows() const override { return 2 * n_cus * (128 / HW); }
     void forward(hipStream_t s, const int8_t* in, float* policy, float* value, int n, bool timing, int p0 = 0) override {
         forward_trunk(s, in, n, timing, p0);

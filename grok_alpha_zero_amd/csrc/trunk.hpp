@@ -136,12 +136,18 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lhi = lane >> 5;
     const int HW = a.H * a.W;
+    // Divisions by the board's width / size are multiplications by a 16-bit reciprocal, formed ONCE (exact for n < 65536 / d: cells and image rows
+    // are < 272).  Round 3: as plain `/` and `%` on run-time values the prologue, the stem and the heads held ~40 64-bit scalar divisions (m0 / HW, one
+    // per locate() call: ~200 scalar instructions each) and ~45 32-bit vector ones — a third of the stem phase's instructions.
+    const unsigned inv_w = (65536u + (unsigned)a.W - 1u) / (unsigned)a.W, inv_hw = (65536u + (unsigned)HW - 1u) / (unsigned)HW;
+    auto cell_yx = [&](const int cell, int& y, int& x) { y = (int)(((unsigned)cell * inv_w) >> 16); x = cell - y * a.W; };
+    const int board0 = (int)((unsigned)m0_ / (unsigned)HW);      // first board of the tile (natural order; the completion queue names games instead)
     // image row -> (cell of its board, global row); false for padding rows and rows beyond the batch.  Natural layout: image row q <-> global row
     // m0 + q; SKIPSET variants: board b of the tile starts at image row byte b of boffp (TrunkArgs::boff)
     auto locate = [&](const int row, int& cell, long& grow, const unsigned bo = 0xFFFFFFFFu) -> bool {      // bo: see the heads phase
         const unsigned boffq = bo == 0xFFFFFFFFu ? boffp : bo;
         if constexpr (SKIPSET == 0) {
-            cell = row % HW; grow = m0 + row;
+            cell = row - (int)(((unsigned)row * inv_hw) >> 16) * HW; grow = m0 + row;
             return row < tile_rows && grow < a.M;
         } else {
             bool ok = false; cell = 0; grow = 0;
@@ -151,7 +157,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 if (b * HW < tile_rows && row >= o && row < o + HW) {
                     cell = row - o;
                     // completion queue: board b of the tile is the game its queue entry names (Xt[1 + b], written before the barrier below; -1 = no entry)
-                    const long gb = a.queue ? (long)Xt[1 + b] : m0 / HW + b;
+                    const long gb = a.queue ? (long)Xt[1 + b] : (long)(board0 + b);
                     ok = gb >= 0; grow = gb * HW + cell;
                 }
             }
@@ -218,7 +224,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     // fused launch: "this workgroup's wait ran out" (Xt[0]), workgroup-uniform after the barrier
     if ((STEM || S0) && (a.ready || a.queue)) {     // wait for the tree teams of this tile's boards (see TrunkArgs::ready / queue), for a bounded time
         if (tid == 0) Xt[0] = 0;                    // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
-        const long b = m0 / HW + tid;               // board of the batch = done flag index, or queue entry
+        const long b = (long)board0 + tid;          // board of the batch = done flag index, or queue entry
         if (tid < tile_rows / HW) {
             int game = -1;
             if (b * HW < a.M) {
@@ -265,7 +271,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         unsigned mm = 0;
         int cell; long grow_;
         if (locate(lrow[tm], cell, grow_)) {
-            const int y = cell / a.W, x = cell % a.W;
+            int y, x; cell_yx(cell, y, x);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -391,7 +397,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         unsigned mm = 0;
         int cell; long grow_;
         if (locate(crow_t, cell, grow_)) {
-            const int y = cell / a.W, x = cell % a.W;
+            int y, x; cell_yx(cell, y, x);
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 const int dy = q / 3 - 1, dx = q % 3 - 1;
@@ -900,7 +906,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         int hcell; long hgr;
         const bool hok = locate(hrow, hcell, hgr, boh);
         if (hok) {
-            const int cell = hcell, y = cell / a.W, x = cell % a.W;
+            int y, x; cell_yx(hcell, y, x);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -934,8 +940,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         // lane: cell hrow, channels 8 j + 4 lhi + q: j = 0 policy head, j = 1 value head, j = 2, 3 padding
         const long gr = hgr;
         if (hok) {
-            const unsigned b = (unsigned)gr / (unsigned)HW; const int cell = hcell;
-            const int f = cell * 8 + 4 * lhih;
+            const int f = hcell * 8 + 4 * lhih;     // flat feature index of the board: the output row of board b starts at b HW 8, i.e. element gr 8 + 4 lhi
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float4 bi = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhih);
@@ -944,7 +949,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 float4 o;
                 o.x = fmaxf((hacc[4 * j + 0] + bi.x) * sc.x + sh.x, 0.0f); o.y = fmaxf((hacc[4 * j + 1] + bi.y) * sc.y + sh.y, 0.0f);
                 o.z = fmaxf((hacc[4 * j + 2] + bi.z) * sc.z + sh.z, 0.0f); o.w = fmaxf((hacc[4 * j + 3] + bi.w) * sc.w + sh.w, 0.0f);
-                *reinterpret_cast<float4*>((j ? a.v_feat : a.p_feat) + (size_t)b * (HW * 8) + f) = o;
+                *reinterpret_cast<float4*>((j ? a.v_feat : a.p_feat) + (size_t)gr * 8 + 4 * lhih) = o;
             }
         }
         }
