@@ -913,6 +913,19 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 hmask |= (((unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W) ? 1u : 0u) << t;
             }
         }
+        // the epilogue's per-position parameters (flat BN of both heads: L2 round trips) are requested here, in front of the taps, not behind them
+        float4 hbi[2], hsc[2], hsh[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { hbi[j] = hsc[j] = hsh[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+        if (hok) {
+            const int f = hcell * 8 + 4 * lhih;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                hbi[j] = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhih);
+                hsc[j] = *reinterpret_cast<const float4*>((j ? a.v_fs : a.p_fs) + f);
+                hsh[j] = *reinterpret_cast<const float4*>((j ? a.v_ft : a.p_ft) + f);
+            }
+        }
         if (waveh * 32 < ROWS) {                    // wave-uniform (WN = 4, TM = 3: the fourth wave has no cell tile)
         f32x16 hacc;
 #pragma unroll
@@ -940,12 +953,10 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
         // lane: cell hrow, channels 8 j + 4 lhi + q: j = 0 policy head, j = 1 value head, j = 2, 3 padding
         const long gr = hgr;
         if (hok) {
-            const int f = hcell * 8 + 4 * lhih;     // flat feature index of the board: the output row of board b starts at b HW 8, i.e. element gr 8 + 4 lhi
+            // (flat feature index of the board = hcell 8 + 4 lhi; the output row of board b starts at b HW 8, i.e. the element is gr 8 + 4 lhi)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float4 bi = *reinterpret_cast<const float4*>(a.hbias + 8 * j + 4 * lhih);
-                const float4 sc = *reinterpret_cast<const float4*>((j ? a.v_fs : a.p_fs) + f);
-                const float4 sh = *reinterpret_cast<const float4*>((j ? a.v_ft : a.p_ft) + f);
+                const float4 bi = hbi[j], sc = hsc[j], sh = hsh[j];
                 float4 o;
                 o.x = fmaxf((hacc[4 * j + 0] + bi.x) * sc.x + sh.x, 0.0f); o.y = fmaxf((hacc[4 * j + 1] + bi.y) * sc.y + sh.y, 0.0f);
                 o.z = fmaxf((hacc[4 * j + 2] + bi.z) * sc.z + sh.z, 0.0f); o.w = fmaxf((hacc[4 * j + 3] + bi.w) * sc.w + sh.w, 0.0f);
