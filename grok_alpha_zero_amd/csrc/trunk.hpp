@@ -456,7 +456,8 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                         acc16[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wfr[ks][ct]), *reinterpret_cast<bf16x8*>(&cfr[ks & 1][t]), acc16[ct][t], 0, 0, 0);
                 // the next k-step's reads in the middle of this one's MFMAs: this k-step's fragments are still live, so they cannot
                 // be allocated over them (behind the last MFMA the scheduler does exactly that: prefetch distance zero), and they
-                // issue in the shadow of the MFMAs above
+                // issue in the shadow of the MFMAs above.  (Round 3: in FRONT of the k-step's MFMAs — a whole k-step of distance — the kernel
+                // alone is unchanged, 431 us, and the wave of two game groups gets slower, 462 vs 455 us: not kept)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NC; ++t)
