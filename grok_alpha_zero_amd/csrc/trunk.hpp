@@ -139,15 +139,20 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     // Divisions by the board's width / size are multiplications by a 16-bit reciprocal, formed ONCE (exact for n < 65536 / d: cells and image rows
     // are < 272).  Round 3: as plain `/` and `%` on run-time values the prologue, the stem and the heads held ~40 64-bit scalar divisions (m0 / HW, one
     // per locate() call: ~200 scalar instructions each) and ~45 32-bit vector ones — a third of the stem phase's instructions.
-    const unsigned inv_w = (65536u + (unsigned)a.W - 1u) / (unsigned)a.W, inv_hw = (65536u + (unsigned)HW - 1u) / (unsigned)HW;
-    auto cell_yx = [&](const int cell, int& y, int& x) { y = (int)(((unsigned)cell * inv_w) >> 16); x = cell - y * a.W; };
-    const int board0 = (int)((unsigned)m0_ / (unsigned)HW);      // first board of the tile (natural order; the completion queue names games instead)
+    // The three values live in LDS behind the parameter sets (Xt[4..6], written by thread 0 in front of the first barrier) and are read where they
+    // are used: held in scalar registers across the block loop they cost the edge-tile variants spilled registers (scratch traffic: 67 -> 82 MB
+    // of HBM traffic per launch by counter).
+    auto cell_yx = [&](const int cell, int& y, int& x) { y = (int)(((unsigned)cell * (unsigned)Xt[4]) >> 16); x = cell - y * a.W; };
+    if (tid == 0) {
+        Xt[4] = (int)((65536u + (unsigned)a.W - 1u) / (unsigned)a.W); Xt[5] = (int)((65536u + (unsigned)HW - 1u) / (unsigned)HW);
+        Xt[6] = (int)((unsigned)m0_ / (unsigned)HW);            // first board of the tile (natural order; the completion queue names games instead)
+    }
     // image row -> (cell of its board, global row); false for padding rows and rows beyond the batch.  Natural layout: image row q <-> global row
     // m0 + q; SKIPSET variants: board b of the tile starts at image row byte b of boffp (TrunkArgs::boff)
     auto locate = [&](const int row, int& cell, long& grow, const unsigned bo = 0xFFFFFFFFu) -> bool {      // bo: see the heads phase
         const unsigned boffq = bo == 0xFFFFFFFFu ? boffp : bo;
         if constexpr (SKIPSET == 0) {
-            cell = row - (int)(((unsigned)row * inv_hw) >> 16) * HW; grow = m0 + row;
+            cell = row - (int)(((unsigned)row * (unsigned)Xt[5]) >> 16) * HW; grow = m0 + row;
             return row < tile_rows && grow < a.M;
         } else {
             bool ok = false; cell = 0; grow = 0;
@@ -157,7 +162,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 if (b * HW < tile_rows && row >= o && row < o + HW) {
                     cell = row - o;
                     // completion queue: board b of the tile is the game its queue entry names (Xt[1 + b], written before the barrier below; -1 = no entry)
-                    const long gb = a.queue ? (long)Xt[1 + b] : (long)(board0 + b);
+                    const long gb = a.queue ? (long)Xt[1 + b] : (long)(Xt[6] + b);
                     ok = gb >= 0; grow = gb * HW + cell;
                 }
             }
@@ -224,7 +229,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
     // fused launch: "this workgroup's wait ran out" (Xt[0]), workgroup-uniform after the barrier
     if ((STEM || S0) && (a.ready || a.queue)) {     // wait for the tree teams of this tile's boards (see TrunkArgs::ready / queue), for a bounded time
         if (tid == 0) Xt[0] = 0;                    // tid 0 and the pollers (tid < boards per tile <= 3) are lanes of wave 0: LDS accesses of one wave are in order
-        const long b = (long)board0 + tid;          // board of the batch = done flag index, or queue entry
+        const long b = (long)((unsigned)m0_ / (unsigned)HW) + tid;          // board of the batch = done flag index, or queue entry (in front of the barrier: not from Xt[6])
         if (tid < tile_rows / HW) {
             int game = -1;
             if (b * HW < a.M) {
