@@ -243,7 +243,9 @@ int gaz_engine_timing_reset(gaz_engine* h, int32_t enable);
 /* the kernel priced against the roofline: its name (copied into `name`) and the algorithmic FLOPs of one launch */
 int gaz_engine_dominant_kernel(gaz_engine* h, char* name, int32_t cap, double* flops_per_launch);
 /* sums over the TIMED waves (run_waves brackets every 8th wave: an event record costs a barrier packet): tree-kernel ms, evaluator
- * ms, ms and launch count of the dominant kernel, number of timed waves */
+ * ms, ms and launch count of the dominant kernel, number of timed waves.  With game groups (gaz_engine_config::game_groups) the ms are sums
+ * over the groups' launches — which overlap in time, so they are kernel time, not wall clock — and gaz_engine_dominant_kernel prices ONE group's
+ * launch; a per-kernel roofline is measured on an engine with game_groups = 1 (bench.py does) */
 int gaz_engine_timing_get(gaz_engine* h, double* ms_tree, double* ms_eval, double* ms_dominant, int64_t* n_dominant, int64_t* n_waves);
 
 #ifdef __cplusplus
