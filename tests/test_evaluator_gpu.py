@@ -473,19 +473,21 @@ def test_game_groups_evaluate_and_head_features_cover_all_rows():
     assert np.array_equal(outs[0][0][:700], outs[0][2])
 
 
-@pytest.mark.parametrize("groups,fault", [(2, False), (3, False), (2, True)])
-def test_game_groups_with_fused_launches_in_flight_together_give_identical_games(groups, fault):
+@pytest.mark.parametrize("groups,fault,cache", [(2, False, 0), (3, False, 0), (2, True, 0), (2, False, 16)])
+def test_game_groups_with_fused_launches_in_flight_together_give_identical_games(groups, fault, cache):
     """gaz_engine_config::game_groups (engine.hip GroupEngine, round 3): the games as K groups, each with its own stream, batch and fused tree + trunk
     launch per wave — K launches in flight on the chip at once, each one's trunk workgroups polling only their own group's completion queue.
     Scheduling only: with a games_budget the grouped engine must finish exactly the games of one batch, bit for bit — also while workgroups of the
-    concurrent launches give up waiting (gaz_engine_debug_fused_fault) and the groups fall back to separate launches."""
+    concurrent launches give up waiting (gaz_engine_debug_fused_fault) and the groups fall back to separate launches, and with the evaluation
+    cache (a table per group) against one batch without it."""
     from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
     from grok_alpha_zero_amd.net import Connect4Net
     w = Connect4Net(2, seed=5).eval().export_engine_weights()
     G, budget = 1600, 2000
     got = []
     for k in (groups, 1):
-        eng = SelfPlayEngine("Connect4", G, 24, 14, 4, 3, 2.5, 0.5, seed=29, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192, games_budget=budget, game_groups=k)
+        eng = SelfPlayEngine("Connect4", G, 24, 14, 4, 3, 2.5, 0.5, seed=29, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192, games_budget=budget, game_groups=k,
+                             eval_cache_log2=cache if k > 1 else 0)
         eng.load_weights(w)
         eng.run_waves(30); eng.synchronize()
         st = eng.stats()
