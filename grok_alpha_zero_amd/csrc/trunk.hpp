@@ -69,12 +69,35 @@ struct TrunkArgs {
 // what ResNetEvaluator::forward_trunk launches, as data: used by the fused tree + trunk launch (resnet.hip k_wave_trunk)
 struct TrunkLaunchPlan { TrunkArgs args; int nwg; int mix; unsigned lds_bytes; };
 
-__device__ __forceinline__ float gelu_as(float v) {         // x * Phi(x), Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8)
+// GELU = x * Phi(x), Phi from the Abramowitz-Stegun 7.1.26 erfc polynomial (|err| < 8e-8 on Phi; as bf16 the result differs from the erf form
+// in 0.14 % of the elements of a normal sample, by one ulp).  ONE operation sequence in two forms — explicit fused multiply-adds (the build runs with
+// -ffp-contract=off), v_exp_f32 and v_rcp_f32 — so that the scalar form (k_stem_mfma) and the packed form (two values per v_pk_* instruction: the
+// in-kernel stem's epilogue, round 3: 17.7 k cycles of a workgroup's 264 k were this function) give the same bits.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float gelu_as(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
-    float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    p = 0.5f * p * __expf(-x * x);                 // 0.5 * erfc(x)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(t, p, 1.421413741f); p = __builtin_fmaf(t, p, -0.284496736f); p = __builtin_fmaf(t, p, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f((x * x) * -1.44269504088896340736f);      // exp(-x^2)
+    p = (0.5f * p) * e;                             // 0.5 * erfc(x)
     return v * (v < 0.0f ? p : 1.0f - p);
+}
+__device__ __forceinline__ f32x2_t gelu_as2(f32x2_t v) {
+    const f32x2_t av = {fabsf(v.x), fabsf(v.y)};
+    const f32x2_t x = av * 0.70710678118654752440f;
+    const f32x2_t d = __builtin_elementwise_fma((f32x2_t)(0.3275911f), x, (f32x2_t)(1.0f));
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t)(1.061405429f), (f32x2_t)(-1.453152027f));
+    p = __builtin_elementwise_fma(t, p, (f32x2_t)(1.421413741f)); p = __builtin_elementwise_fma(t, p, (f32x2_t)(-0.284496736f)); p = __builtin_elementwise_fma(t, p, (f32x2_t)(0.254829592f));
+    p = p * t;
+    const f32x2_t q = (x * x) * -1.44269504088896340736f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    p = (p * 0.5f) * e;
+    const f32x2_t one_m = (f32x2_t)(1.0f) - p;
+    const f32x2_t ph = {v.x < 0.0f ? p.x : one_m.x, v.y < 0.0f ? p.y : one_m.y};
+    return v * ph;
 }
 __device__ __forceinline__ unsigned s8x2_to_bf16x2(int lo, int hi) {      // two small integers -> packed bf16 (exact)
     return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
@@ -326,6 +349,7 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 for (int ks2 = 0; ks2 < 6; ++ks2)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&sw[ks2][tn]), *reinterpret_cast<const bf16x8*>(&cf[ks2 % 3]), acc[tm][tn], 0, 0, 0);
             }
+            TR_STAMP(56 + tm);                      // (diagnostic: the stem's planes of cell tile tm loaded, converted and multiplied)
         }
         const float* SH = Ps + TR_PRM;
 #pragma unroll
@@ -338,14 +362,16 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                     const float4 sh = *reinterpret_cast<const float4*>(&SH[c0]);
                     const float4 s = *reinterpret_cast<const float4*>(&Ps[c0]);
                     const float4 t = *reinterpret_cast<const float4*>(&Ps[128 + c0]);
-                    const float v0 = gelu_as(acc[tm][tn][4 * j + 0] + sh.x), v1 = gelu_as(acc[tm][tn][4 * j + 1] + sh.y);
-                    const float v2 = gelu_as(acc[tm][tn][4 * j + 2] + sh.z), v3 = gelu_as(acc[tm][tn][4 * j + 3] + sh.w);
+                    const f32x2_t g01 = gelu_as2(f32x2_t{acc[tm][tn][4 * j + 0] + sh.x, acc[tm][tn][4 * j + 1] + sh.y});
+                    const f32x2_t g23 = gelu_as2(f32x2_t{acc[tm][tn][4 * j + 2] + sh.z, acc[tm][tn][4 * j + 3] + sh.w});
+                    const float v0 = g01.x, v1 = g01.y, v2 = g23.x, v3 = g23.y;
                     const uint2 xn = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
                     *reinterpret_cast<uint2*>(Xb + o) = xn;
                     const float a0 = fmaxf(__uint_as_float(xn.x << 16) * s.x + t.x, 0.0f), a1 = fmaxf(__uint_as_float(xn.x & 0xFFFF0000u) * s.y + t.y, 0.0f);
                     const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t.w, 0.0f);
                     *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
                 }
+        TR_STAMP(58);                               // (diagnostic: this wave's share of the stem's GELU epilogue written)
     } else if (B0) {
         // the operand of conv1 is made further down (preact_half), half by half
     } else {

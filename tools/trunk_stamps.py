@@ -30,6 +30,11 @@ def phase(name, i0, i1):
 
 phase("image DMA wait", 0, 1)
 phase("block 0 operand", 1, 2)
+if (cyc[:, 58] > 0).all():                                 # stem inside the launch: its sub-phases (wave 0)
+    phase("  stem: planes + MFMA tile 0", 1, 56)
+    phase("  stem: planes + MFMA tile 1", 56, 57)
+    phase("  stem: GELU epilogue", 57, 58)
+    phase("  stem: barrier", 58, 2)
 names = ["conv1 taps", "barrier", "h write + barrier", "conv2 taps", "barrier", "epilogue + barrier"]
 tot = np.zeros(6)
 for b in range(nb):
