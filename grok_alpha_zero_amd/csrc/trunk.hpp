@@ -349,7 +349,6 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                 for (int ks2 = 0; ks2 < 6; ++ks2)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&sw[ks2][tn]), *reinterpret_cast<const bf16x8*>(&cf[ks2 % 3]), acc[tm][tn], 0, 0, 0);
             }
-            TR_STAMP(56 + tm);                      // (diagnostic: the stem's planes of cell tile tm loaded, converted and multiplied)
         }
         const float* SH = Ps + TR_PRM;
 #pragma unroll
@@ -371,7 +370,6 @@ __device__ __forceinline__ void trunk_tile(const TrunkArgs& a, const long m0_, c
                     const float a2 = fmaxf(__uint_as_float(xn.y << 16) * s.z + t.z, 0.0f), a3 = fmaxf(__uint_as_float(xn.y & 0xFFFF0000u) * s.w + t.w, 0.0f);
                     *reinterpret_cast<uint2*>(Ab + o) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
                 }
-        TR_STAMP(58);                               // (diagnostic: this wave's share of the stem's GELU epilogue written)
     } else if (B0) {
         // the operand of conv1 is made further down (preact_half), half by half
     } else {
