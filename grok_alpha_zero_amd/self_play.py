@@ -322,9 +322,10 @@ def record_to_samples(game_class, rec):
 
 def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, *, n_games=1024, seed=None, weights=None,
                   device=0, slot_offset=0, hash_salt=0, lib_path=None, progress=None, eval_cache_log2=22, generation=None,
-                  first_game_seq=None, allow_synthetic=False, engine_stats=None):
+                  first_game_seq=None, allow_synthetic=False, engine_stats=None, game_groups=0):
     """Generate `games_per_generation - game_stats[2]` self-play games into `folder_path` (Self_Play.py:259-272).
-    (`engine_stats`: a dict that receives the engine's counters — evaluator calls, simulations, waves — when the generation is done.)
+    (`engine_stats`: a dict that receives the engine's counters — evaluator calls, simulations, waves — when the generation is done.
+    `game_groups`: gaz_engine_config.game_groups, scheduling only: 0 = the library's choice, 1 = one batch.)
     `configs` = (build_config, train_config[, optimizer_config]).  `weights` = dict from net.export_engine_weights()
     (generation > 0); generation 0 (folder name "0") plays with the synthetic evaluator like the reference's
     session=None dummy (Self_Play.py:40, MCTS.py:237-241).
@@ -382,7 +383,7 @@ def run_self_play(game_class, configs, folder_path, per_process_wait_time=1e-3, 
                          games_budget=games_left, first_game_seq=first_game_seq,
                          # Self_Play.py:35,100-112: every MCTS.run gets time_limit = MCTS_time_limit next to its iteration limit; the engine keeps a
                          # wall clock per game and move (PUCT) / runs 3 x legal moves iterations per move (Gumbel, MCTS_Gumbel.py:576-578)
-                         move_time_limit=float(train_config.get("MCTS_time_limit") or 0.0))
+                         move_time_limit=float(train_config.get("MCTS_time_limit") or 0.0), game_groups=game_groups)
     if train_config.get("MCTS_time_limit") and gumbel:
         logging.getLogger("grok_alpha_zero_amd").warning("Time limit isn't allowed for gumbel MCTS defaulting to use 3 * len_legal_actions")   # MCTS_Gumbel.py:578
     logging.getLogger("grok_alpha_zero_amd").info("run_self_play: generation %d, %d games on %d slots, evaluator = %s, game_seq from %d",

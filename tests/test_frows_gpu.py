@@ -62,6 +62,32 @@ def test_run_self_play_on_hip_writes_the_oracles_games(tmp_path, oracle, gumbel)
     assert [gs[3], gs[4], gs[5]] == [winners.count(-1), winners.count(0), winners.count(1)]
 
 
+def test_run_self_play_with_game_groups_writes_the_same_generation(tmp_path):
+    """run_self_play at a size where the engine splits the games into two groups on its own (3072 slots, ResNet evaluator, evaluation cache on,
+    budget no multiple of the slots, the tail repacked): the generation's file must hold exactly the games a one-batch engine writes — same
+    admitted set, same states / policies / values — and the same game_stats."""
+    _gpu()
+    from grok_alpha_zero_amd.games import GAMES
+    from grok_alpha_zero_amd.net import Connect4Net
+    from grok_alpha_zero_amd.self_play import ReplayStore, run_self_play
+    w = Connect4Net(2, seed=9).eval().export_engine_weights()
+    G, games = 3072, 3400
+    build = dict(num_resnet_layers=2, num_filters=128)
+    train = dict(games_per_generation=games, MCTS_iteration_limit=16, max_actions=12, num_explore_actions_first=4, num_explore_actions_second=3,
+                 c_puct_init=2.5, dirichlet_alpha=0.5)
+    out = {}
+    for groups in (0, 1):
+        folder = str(tmp_path / f"g{groups}" / "1")
+        store = ReplayStore(folder); store.create()
+        st = {}
+        assert run_self_play(GAMES["Connect4"], (build, train), folder, n_games=G, seed=11, weights=w, engine_stats=st, game_groups=groups) == games
+        assert st["game_groups"] == (2 if groups == 0 else 1)
+        file_games = _games_in_file(store, 2)
+        assert len(file_games) == games
+        out[groups] = (sorted((b.tobytes(), p.tobytes(), v.tobytes()) for b, p, v in file_games), store.game_stats().tolist(), st["evals"], st["sims"])
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and out[0][2:] == out[1][2:]
+
+
 def test_orchestrator_run_on_hip(tmp_path, oracle):
     """f4: orchestrator.Run (<Game>/main.py:312-352, self-play half) on the HIP engine: generation folders, resume from game_stats[2],
     and a generation > 0 played with the HIP ResNet evaluator (weights_fn) — its games equal the oracle's fed by that same network."""
