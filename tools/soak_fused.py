@@ -13,8 +13,11 @@ waves = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
 cache = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 w = Connect4Net(6, seed=0).eval().export_engine_weights()
 out = []
-for fused in (True, False):
-    eng = SelfPlayEngine("Connect4", G, 200, 42, 8, 7, 2.5, 0.5, seed=1234, evaluator=EVAL_RESNET, net_blocks=6, ring_capacity=4 * G, eval_cache_log2=cache)
+# (round 3) three runs: the default (game groups where the library chooses them: two fused launches in flight together), one batch fused, and the
+# default's grouping with separate launches
+for fused, groups in ((True, 0), (True, 1), (False, 0)):
+    eng = SelfPlayEngine("Connect4", G, 200, 42, 8, 7, 2.5, 0.5, seed=1234, evaluator=EVAL_RESNET, net_blocks=6, ring_capacity=4 * G, eval_cache_log2=cache,
+                         game_groups=groups)
     eng.load_weights(w); eng.set_fused_wave(fused)
     t0 = time.time(); recs = {}
     for _ in range(waves // 200):
@@ -25,10 +28,14 @@ for fused in (True, False):
                 h.update(np.ascontiguousarray(r[k]).tobytes())
             recs[(r["slot"], r["game_seq"])] = (r["T"], r["winner"], h.hexdigest())
     st = eng.stats(); eng.close()
-    print(f"fused={fused}: {len(recs)} games finished in {time.time() - t0:.1f} s, {st['evals']} evaluations ({st['cache_hits']} cache hits), fused flag {st['fused_wave']}", flush=True)
+    print(f"fused={fused} groups={st['game_groups']}: {len(recs)} games finished in {time.time() - t0:.1f} s, {st['evals']} evaluations ({st['cache_hits']} cache hits), "
+          f"fused flag {st['fused_wave']}, workgroups that gave up {st['fused_faults']}", flush=True)
     out.append(recs)
-a, b = out
-common = set(a) & set(b)
-bad = [k for k in common if a[k] != b[k]]
-print(f"{len(common)} games in both runs, {len(set(a) ^ set(b))} only in one (finished in the last launches), mismatching records: {len(bad)}")
-sys.exit(1 if bad or len(common) < 100 else 0)
+a = out[0]
+fail = False
+for name, b in (("one batch, fused", out[1]), ("separate launches", out[2])):
+    common = set(a) & set(b)
+    bad = [k for k in common if a[k] != b[k]]
+    print(f"default vs {name}: {len(common)} games in both runs, {len(set(a) ^ set(b))} only in one (finished in the last launches), mismatching records: {len(bad)}")
+    fail = fail or bool(bad) or len(common) < 100
+sys.exit(1 if fail else 0)
