@@ -890,6 +890,7 @@ template <class G> struct EngineT : gaz_engine {
         *n_out = 0;
         if (E.ring_cap <= 0) return 0;
         HIP_OK(hipStreamSynchronize(stream));
+        if (poll_fuse_fault()) return 1;            // a host synchronisation point like the others: a caller that only ever drains must still get the fallback
         uint32_t head[2];
         HIP_OK(hipMemcpy(head, E.ring_head, sizeof(head), hipMemcpyDeviceToHost));
         uint32_t avail = head[0] - ring_consumed;

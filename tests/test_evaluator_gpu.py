@@ -454,6 +454,28 @@ def test_fused_tree_and_trunk_launch_gives_identical_games(search, monkeypatch):
             np.testing.assert_array_equal(np.asarray(a[k][f]), np.asarray(b[k][f]), err_msg=f"{k} {f}")
 
 
+def test_fused_launch_fallback_also_happens_for_a_caller_that_only_drains():
+    """gaz_engine_drain_finished is a host synchronisation point like synchronize / get_stats: a self-play loop that only ever runs waves and drains
+    (self_play.run_self_play) must get the fallback to separate launches after trunk workgroups gave up — otherwise every later fused launch
+    finds the fault counter set, gives up at once, and no game ever moves again."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=5).eval().export_engine_weights()
+    eng = SelfPlayEngine("Connect4", 1600, 24, 14, 4, 3, 2.5, 0.5, seed=23, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=8192, games_budget=1600, game_groups=2)
+    eng.load_weights(w)
+    eng.run_waves(40); eng.synchronize()
+    eng.debug_fused_fault(5)
+    recs = []
+    for _ in range(200):
+        eng.run_waves(50)
+        recs += eng.drain_finished(8192)            # the only synchronisation in the loop
+        if len(recs) >= 1600:
+            break
+    st = eng.stats()
+    eng.close()
+    assert len(recs) == 1600 and st["fused_faults"] > 0 and st["fused_wave"] == 0, (len(recs), st)
+
+
 def test_game_groups_evaluate_and_head_features_cover_all_rows():
     """gaz_engine_evaluate / gaz_engine_read_head_features on a grouped engine: rows [first[c], first[c + 1]) go through group c — the outputs must be
     those of one batch, row for row (rows are independent of the batch they are evaluated in)."""
