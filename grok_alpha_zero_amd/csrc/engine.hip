@@ -525,13 +525,20 @@ template <class G> struct EngineT : gaz_engine {
         HIP_OK(hipMemcpy(&n, d_fault, sizeof(n), hipMemcpyDeviceToHost));
         if (n) {
             fuse_faults += (uint64_t)n; n = 0; fuse_state = 0; debug_fault_mod = 0;      // (the test hook injects until the fault has been seen)
+            fault_wave = waves_launched; fault_strikes++;
             HIP_OK(hipMemcpy(d_fault, &n, sizeof(n), hipMemcpyHostToDevice));
             fprintf(stderr, "[gaz_engine] fused tree + trunk launch: %llu trunk workgroup(s) gave up waiting for their games (dispatch order not as assumed); "
-                            "falling back to separate launches\n", (unsigned long long)fuse_faults);
+                            "falling back to separate launches%s\n", (unsigned long long)fuse_faults,
+                    fault_strikes <= REARM_STRIKES ? " (the one-launch form is tried again after 20000 waves)" : " for good");
         }
         return 0;
     }
+    // A give-up can be a transient — with two game groups, two launches in flight can for once hold each other's slots — and separate launches cost a
+    // grouped engine a fifth of its rate: after REARM_WAVES waves without the one-launch form it is tried again, at most REARM_STRIKES times.
+    int64_t waves_launched = 0, fault_wave = 0; int fault_strikes = 0;
+    static constexpr int64_t REARM_WAVES = 20000; static constexpr int REARM_STRIKES = 2;
     bool can_fuse() {
+        if (fuse_state == 0 && fault_strikes > 0 && fault_strikes <= REARM_STRIKES && d_queue_or_done() && waves_launched - fault_wave >= REARM_WAVES) fuse_state = 1;
         if (fuse_state >= 0) return fuse_state == 1;
         fuse_state = 0;
         static const bool off = getenv("GAZ_FUSE_WAVE") && atoi(getenv("GAZ_FUSE_WAVE")) == 0;
@@ -553,6 +560,7 @@ template <class G> struct EngineT : gaz_engine {
         return true;
     }
 
+    bool d_queue_or_done() const { return d_done != nullptr; }      // the fused launch's buffers exist: it had been running before the fault
     bool fuse_enabled = true;
     int set_fused_wave(int on) override { fuse_enabled = on != 0; return 0; }
     bool ensure_skip_buffers() {
@@ -614,6 +622,7 @@ template <class G> struct EngineT : gaz_engine {
     }
 
     int one_wave(bool with_eval) {
+        ++waves_launched;
         if (with_eval && eval && fuse_enabled && can_fuse()) {
             const bool timing = this->timing && n_waves_total % TIMING_STRIDE == 0 && ev.size() + 4 <= MAX_TIMING_EVENTS;
             // diagnostic: GAZ_FUSED_STAMPS=<file>[:n] -> wall-clock stamps of every block of the n-th fused launch (tools/fused_timeline.py)

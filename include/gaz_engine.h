@@ -205,7 +205,8 @@ int gaz_engine_get_stats(gaz_engine* h, uint64_t out[16]);  /* [0..5] game_stats
                                                                [10] evaluations answered by the evaluation cache, [11] groups of the group pipeline (0 = off),
                                                                [12] 1 = tree step and trunk kernel run as ONE fused launch,
                                                                [13] trunk workgroups of fused launches that gave up waiting for their games (see
-                                                                    gaz_engine_debug_fused_fault); non-zero = the engine has fallen back to separate launches,
+                                                                    gaz_engine_debug_fused_fault); non-zero = the engine has fallen back to separate launches ([12] says whether it still is: the
+                                                                    one-launch form is tried again after 20000 waves, at most twice),
                                                                [14] game groups (gaz_engine_config::game_groups as resolved; 0 = one batch): with groups, [0..8], [10], [13]
                                                                     are sums over the groups and [12] says that every group runs the one-launch form */
 int gaz_engine_synchronize(gaz_engine* h);

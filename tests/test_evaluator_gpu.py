@@ -476,6 +476,38 @@ def test_fused_launch_fallback_also_happens_for_a_caller_that_only_drains():
     assert len(recs) == 1600 and st["fused_faults"] > 0 and st["fused_wave"] == 0, (len(recs), st)
 
 
+def test_fused_launch_is_tried_again_after_a_transient_fault():
+    """After trunk workgroups gave up, the engine runs separate launches — but not for good on the first occasion: a give-up can be a transient
+    (two game groups' launches holding each other's slots), and separate launches cost a grouped engine a fifth of its rate.  20000 waves later the
+    one-launch form is back (at most twice); the games do not notice either switch."""
+    from grok_alpha_zero_amd.engine import SelfPlayEngine, EVAL_RESNET
+    from grok_alpha_zero_amd.net import Connect4Net
+    w = Connect4Net(2, seed=5).eval().export_engine_weights()
+    got = []
+    for fault in (True, False):
+        eng = SelfPlayEngine("Connect4", 512, 24, 14, 4, 3, 2.5, 0.5, seed=31, evaluator=EVAL_RESNET, net_blocks=2, ring_capacity=4096, games_budget=3000)
+        eng.load_weights(w)
+        eng.run_waves(40); eng.synchronize()
+        if fault:
+            eng.debug_fused_fault(5); eng.run_waves(8)
+            st = eng.stats()
+            assert st["fused_faults"] > 0 and st["fused_wave"] == 0, st
+            seen = st["fused_faults"]
+        recs = []
+        for _ in range(22):
+            eng.run_waves(1000)
+            recs += eng.drain_finished(4096)
+        st = eng.stats()
+        assert st["fused_wave"] == 1 and (not fault or st["fused_faults"] == seen), st
+        got.append({(r["slot"], r["game_seq"]): r for r in recs})
+        eng.close()
+    a, b = got
+    assert len(a) == 3000 and set(a) == set(b)
+    for key in a:
+        for f in ("actions", "root_N", "root_W", "policies", "q", "evals"):
+            np.testing.assert_array_equal(np.asarray(a[key][f]), np.asarray(b[key][f]), err_msg=f"{key} {f}")
+
+
 def test_game_groups_evaluate_and_head_features_cover_all_rows():
     """gaz_engine_evaluate / gaz_engine_read_head_features on a grouped engine: rows [first[c], first[c + 1]) go through group c — the outputs must be
     those of one batch, row for row (rows are independent of the batch they are evaluated in)."""
