@@ -457,6 +457,12 @@ def main():
                                                     f"{groups} launches in flight together — a group's trunk tiles fill the chip while the other group's tree step starts and its heads "
                                                     "run.  launch_us_per_group is the duration of one group's launch while it shares the chip (overlapping: not a price); "
                                                     "wave_us_all_groups is wall clock per wave of all games; trunk_kernel_alone_us the MFMA kernel over all games on an otherwise idle chip")
+                # the whole wave priced like the kernel: every row of every wave (tree step, heads, launch gaps and rows without a request included)
+                wave_s = dt / max(steps * args.waves_per_step, 1)
+                roof["whole_wave"] = dict(us=wave_s * 1e6, tflops=kflops / wave_s / 1e12, frac=kflops / wave_s / 1e12 / PEAK_BF16_TFLOPS,
+                                          frac_useful_rows=evals / world * (kflops / G) / dt / 1e12 / PEAK_BF16_TFLOPS,
+                                          note="flops_per_launch (all rows of one rank's batch) over the wall clock per wave of the headline segment: what the chip delivers end to "
+                                               "end, tree step, heads and gaps included; frac_useful_rows counts only the rows that carried a request")
             # the tree kernel against ITS roofline (north_star: "rocprof HBM GB/s on tree kernels"): algorithmic bytes per launch = SURVEY 8d's bytes per
             # simulation x the simulations one launch runs (measured), over the launch duration of the separately-launched tree step (HIP events);
             # counter bytes from the committed --pmc passes.  It is a chain of dependent round trips, not a stream: the fraction says so.
