@@ -16,5 +16,7 @@ ph("wait (0 -> 1)", 0, 1); ph("stem + block-0 operand (1 -> 2)", 1, 2)
 for b in range(10):
     base = 3 + 6 * b
     if (cyc[:, base + 5] > 0).any(): ph(f"block {b} (prev -> +5)", 2 if b == 0 else base - 1, base + 5)
-ph("copy out (last -> 63)", 3 + 6 * 9 + 5, 63); ph("whole (0 -> 63)", 0, 63)
+ph("heads / copy out (56 -> 63)", 56, 63)
+for a_, b_, n_ in ((56, 57, "gh: setup"), (57, 58, "gh: barrier"), (58, 59, "gh: preact + barrier"), (59, 60, "gh: policy taps"), (60, 61, "gh: policy out + value taps"), (61, 63, "gh: value out")):
+    if (cyc[:, b_] > 0).all() and (cyc[:, a_] > 0).all(): ph(n_, a_, b_); ph("whole (0 -> 63)", 0, 63)
 PY
