@@ -219,8 +219,9 @@ int gaz_engine_set_fused_wave(gaz_engine* h, int32_t on);
 /* The fused launch hands leaf rows from tree blocks to trunk workgroups INSIDE one running kernel, which assumes that the tree blocks (lowest
  * block indices) become resident before the trunk workgroups that wait for them — HIP promises no dispatch order.  The wait is therefore
  * bounded (20 ms): a trunk workgroup that runs out of time leaves its boards unevaluated and marks them, the games keep their requests
- * pending and are evaluated by the next wave (no result changes), and at its next synchronisation point the engine switches to separate
- * launches for good (get_stats [13] counts the workgroups that gave up).  This hook makes every trunk workgroup with index % mod == 1 behave
+ * pending and are evaluated by the next wave (no result changes), and at its next synchronisation point (synchronize, get_stats,
+ * drain_finished) the engine switches to separate launches (get_stats [13] counts the workgroups that gave up) — for 20000 waves, then the one-launch
+ * form is tried again; after the third give-up for good.  This hook makes every trunk workgroup with index % mod == 1 behave
  * as if its wait had timed out (mod = 0: off), so that the recovery path can be tested where the assumption holds. */
 int gaz_engine_debug_fused_fault(gaz_engine* h, int32_t mod);
 
